@@ -1,0 +1,262 @@
+"""ctypes binding of libheatflow_hip.so (include/heatflow_hip.h).
+
+This is the only device path: there is no CPU fallback.  If the shared library
+is missing or no HIP device is present, construction raises ``HipUnavailable``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libheatflow_hip.so")
+
+HF_OK, HF_ERR_ARG, HF_ERR_STATE, HF_ERR_HIP, HF_ERR_NOCONV, HF_ERR_ALLOC = 0, -1, -2, -3, -4, -5
+ASM_LDS_ATOMIC, ASM_LDS_COLORED, ASM_GLOBAL_ATOMIC = 0, 1, 2
+K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS = range(6)
+
+EXPORTS = [
+    "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_materials",
+    "hf_set_dirichlet", "hf_assemble", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
+    "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_last_gpu_ms",
+]
+
+
+class HipUnavailable(RuntimeError):
+    """libheatflow_hip.so is not built or no HIP device is usable."""
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"heatflow_hip error {code}: {msg}")
+        self.code = code
+
+
+class NotConverged(HipError):
+    pass
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/heatflow_hip.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc", "heatflow_hip.hip")
+    hdr = os.path.join(_HERE, "..", "include", "heatflow_hip.h")
+    if not force and os.path.isfile(LIB_PATH):
+        newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "libheatflow_hip.so"]
+    if force:
+        cmd.insert(1, "-B")
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout, res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("building libheatflow_hip.so failed:\n" + res.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the library and declare the prototypes (no device is touched)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HipUnavailable(f"{LIB_PATH} not found - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "or `make -C heatflow_amd/csrc`")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    lib.hf_version.restype = C.c_char_p
+    lib.hf_last_error.restype = C.c_char_p
+    lib.hf_last_error.argtypes = [vp]
+    protos = {
+        "hf_create": [C.c_int, C.POINTER(vp)],
+        "hf_destroy": [vp],
+        "hf_set_mesh": [vp, i32, i32, pd, pi, pi],
+        "hf_set_materials": [vp, i32, pi, pd, pd],
+        "hf_set_dirichlet": [vp, i32, pi],
+        "hf_assemble": [vp, dbl, i32],
+        "hf_set_state": [vp, pd],
+        "hf_get_state": [vp, pd],
+        "hf_sample": [vp, i32, pi, pd],
+        "hf_step": [vp, pd, dbl, dbl, i32, pi, pd],
+        "hf_run": [vp, i32, pd, dbl, dbl, i32, i32, pi, pd, pi],
+        "hf_get_sizes": [vp, pi, pi, C.POINTER(i64), pi],
+        "hf_get_csr": [vp, pi, pi, pd, pd],
+        "hf_spmv": [vp, i32, pd, pd],
+        "hf_time_kernel": [vp, i32, i32, pd],
+        "hf_last_gpu_ms": [vp, pd],
+    }
+    for name, args in protos.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _pi(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class HeatflowHIP:
+    """One solver context = one HIP device + one stream (not thread-safe)."""
+
+    def __init__(self, device_id=0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        rc = self._lib.hf_create(int(device_id), C.byref(self._ctx))
+        if rc != HF_OK:
+            msg = self._lib.hf_last_error(self._ctx).decode() if self._ctx else "no usable HIP device"
+            if self._ctx:
+                self._lib.hf_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+            raise HipUnavailable(f"hf_create(device {device_id}) failed ({rc}): {msg}")
+        self.n = self.n_e = self.n_bc = 0
+        self.nnz = 0
+
+    # -- lifetime ------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.hf_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc == HF_OK:
+            return
+        msg = self._lib.hf_last_error(self._ctx).decode()
+        if rc == HF_ERR_NOCONV:
+            raise NotConverged(rc, msg)
+        if rc == HF_ERR_ARG:
+            raise ValueError(f"heatflow_hip: {msg}")
+        raise HipError(rc, msg)
+
+    # -- set-up --------------------------------------------------------------------------
+    def set_mesh(self, coords, tris, tags):
+        zr, tri, tag = _f64(coords), _i32(tris), _i32(tags)
+        if zr.ndim != 2 or zr.shape[1] != 2 or tri.ndim != 2 or tri.shape[1] != 3 or tag.shape != (tri.shape[0],):
+            raise ValueError("set_mesh: coords (n,2), tris (n_e,3), tags (n_e,) expected")
+        self._check(self._lib.hf_set_mesh(self._ctx, zr.shape[0], tri.shape[0], _pd(zr), _pi(tri), _pi(tag)))
+        self._refresh_sizes()
+
+    def _refresh_sizes(self):
+        n, ne, nbc, nnz = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        self._check(self._lib.hf_get_sizes(self._ctx, C.byref(n), C.byref(ne), C.byref(nnz), C.byref(nbc)))
+        self.n, self.n_e, self.nnz, self.n_bc = n.value, ne.value, nnz.value, nbc.value
+
+    def set_materials(self, tags, kappa, rho_c):
+        t, k, c = _i32(tags), _f64(kappa), _f64(rho_c)
+        if not (t.shape == k.shape == c.shape) or t.ndim != 1:
+            raise ValueError("set_materials: three 1-D arrays of equal length expected")
+        self._check(self._lib.hf_set_materials(self._ctx, len(t), _pi(t), _pd(k), _pd(c)))
+
+    def set_dirichlet(self, dofs):
+        d = _i32(dofs)
+        self._check(self._lib.hf_set_dirichlet(self._ctx, len(d), _pi(d) if len(d) else None))
+        self._refresh_sizes()
+
+    def assemble(self, dt, mode=ASM_LDS_ATOMIC):
+        self._check(self._lib.hf_assemble(self._ctx, float(dt), int(mode)))
+
+    # -- state ---------------------------------------------------------------------------
+    def set_state(self, u):
+        u = _f64(u)
+        if u.shape != (self.n,):
+            raise ValueError(f"set_state: expected {self.n} values")
+        self._check(self._lib.hf_set_state(self._ctx, _pd(u)))
+
+    def get_state(self):
+        u = np.empty(self.n, dtype=np.float64)
+        self._check(self._lib.hf_get_state(self._ctx, _pd(u)))
+        return u
+
+    def sample(self, nodes):
+        idx = _i32(nodes)
+        out = np.empty(len(idx), dtype=np.float64)
+        self._check(self._lib.hf_sample(self._ctx, len(idx), _pi(idx), _pd(out)))
+        return out
+
+    # -- time stepping -------------------------------------------------------------------
+    def step(self, g_bc, rtol=1e-10, atol=0.0, max_it=20000):
+        g = _f64(g_bc)
+        if g.shape != (self.n_bc,):
+            raise ValueError(f"step: expected {self.n_bc} boundary values")
+        it, res = C.c_int32(), C.c_double()
+        rc = self._lib.hf_step(self._ctx, _pd(g) if self.n_bc else None, rtol, atol, int(max_it), C.byref(it), C.byref(res))
+        self.last_iters, self.last_resid = it.value, res.value
+        self._check(rc)
+        return it.value, res.value
+
+    def run(self, g_all, rtol=1e-10, atol=0.0, max_it=20000, nodes=None):
+        g = _f64(g_all)
+        if g.ndim != 2 or g.shape[1] != self.n_bc:
+            raise ValueError(f"run: g_all must be (n_steps, {self.n_bc})")
+        nsteps = g.shape[0]
+        idx = _i32(nodes) if nodes is not None and len(nodes) else None
+        ns = 0 if idx is None else len(idx)
+        samples = np.empty((nsteps, ns), dtype=np.float64)
+        iters = np.zeros(nsteps, dtype=np.int32)
+        rc = self._lib.hf_run(self._ctx, nsteps, _pd(g) if self.n_bc else None, rtol, atol, int(max_it), ns, _pi(idx),
+                              _pd(samples) if ns else None, _pi(iters))
+        self.last_run_iters = iters
+        self._check(rc)
+        return samples, iters
+
+    # -- inspection ----------------------------------------------------------------------
+    def get_csr(self, values=True):
+        rowptr = np.empty(self.n + 1, dtype=np.int32)
+        colidx = np.empty(self.nnz, dtype=np.int32)
+        A = np.empty(self.nnz, dtype=np.float64) if values else None
+        M = np.empty(self.nnz, dtype=np.float64) if values else None
+        self._check(self._lib.hf_get_csr(self._ctx, _pi(rowptr), _pi(colidx), _pd(A), _pd(M)))
+        return rowptr, colidx, A, M
+
+    def spmv(self, x, which=0):
+        x = _f64(x)
+        y = np.empty(self.n, dtype=np.float64)
+        self._check(self._lib.hf_spmv(self._ctx, int(which), _pd(x), _pd(y)))
+        return y
+
+    def time_kernel(self, which, reps=50):
+        ms = C.c_double()
+        self._check(self._lib.hf_time_kernel(self._ctx, int(which), int(reps), C.byref(ms)))
+        return ms.value
+
+    def last_gpu_ms(self):
+        ms = C.c_double()
+        self._check(self._lib.hf_last_gpu_ms(self._ctx, C.byref(ms)))
+        return ms.value
+
+    @staticmethod
+    def version():
+        return load_library().hf_version().decode()

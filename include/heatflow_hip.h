@@ -1,0 +1,124 @@
+/*
+ * heatflow_hip.h - C ABI of libheatflow_hip.so (MI355X / gfx950, HIP).
+ *
+ * Drop-in boundary for the hot path of cebarker1000/heatflow.  The reference has no
+ * FFI layer: its drivers call dolfinx / PETSc directly from Python.  Each entry point
+ * below names the reference call(s) it stands in for (file:line in the reference):
+ *
+ *   hf_set_mesh        gmshio.model_to_mesh(...)            run_with_diamond.py:240-245
+ *                      fem.functionspace(domain, P1 / DG0)  run_with_diamond.py:279-280
+ *   hf_set_materials   kappa.x.array[:] / rho_cv.x.array[:] run_with_diamond.py:286-301
+ *   hf_set_dirichlet   fem.dirichletbc(g, row_dofs) x 4     dirichlet_bc/bc.py:104-113,
+ *                                                           run_with_diamond.py:362-374
+ *   hf_assemble        fem.form(lhs) + assemble_matrix(lhs_form, bcs) + KSP/PC setup
+ *                                                           run_with_diamond.py:328-337, 381-394
+ *   hf_set_state       u_n.x.array[:] = ic_temp             run_with_diamond.py:317-319
+ *   hf_step            b.set(0); assemble_vector(b, rhs_form); apply_lifting; ghostUpdate;
+ *                      set_bc; solver.solve(b, u_n)         run_with_diamond.py:474-481
+ *   hf_sample          u_n.x.array[node_idx]                run_with_diamond.py:485-493
+ *   hf_get_state       u_n.x.array (what xdmf.write_function would write)   :483-484
+ *
+ * Conventions
+ *   - All functions return 0 (HF_OK) or a negative HF_ERR_* code; hf_last_error(ctx)
+ *     returns a message for the last failure on that context.
+ *   - Host pointers are borrowed for the duration of the call only and copied to the
+ *     device; outputs go to caller-allocated host buffers.  No torch / numpy types.
+ *   - float64 values, int32 indices.  Node coordinates are (z, r) pairs: mesh x = z
+ *     (axial), mesh y = r (radial), weight r = x[1] as in run_with_diamond.py:321-322.
+ *   - One ctx = one HIP device + one stream.  A ctx is not thread-safe; different
+ *     ctxs may be driven from different threads or processes (one per GPU).
+ *   - There is no CPU fallback: without a HIP device hf_create fails.
+ */
+#ifndef HEATFLOW_HIP_H
+#define HEATFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hf_ctx hf_ctx;
+
+enum {
+  HF_OK = 0,
+  HF_ERR_ARG = -1,      /* bad argument (null pointer, index out of range, ...) */
+  HF_ERR_STATE = -2,    /* call out of order (e.g. hf_step before hf_assemble) */
+  HF_ERR_HIP = -3,      /* a HIP runtime call failed; see hf_last_error */
+  HF_ERR_NOCONV = -4,   /* PCG hit max_it (or broke down) before reaching the tolerance */
+  HF_ERR_ALLOC = -5
+};
+
+/* Assembly variants (all are per-element kernels, results agree to rounding):
+ *   HF_ASM_LDS_ATOMIC    a workgroup owns 256 CSR rows, stages their value slab in LDS,
+ *                        scatter-adds the incident elements with LDS f64 atomics and
+ *                        streams the slab out once (coalesced).  Default.
+ *   HF_ASM_LDS_COLORED   same staging, elements processed colour by colour with plain
+ *                        LDS read-modify-write: bitwise reproducible.
+ *   HF_ASM_GLOBAL_ATOMIC one thread per element, f64 atomics straight into global CSR
+ *                        (baseline / cross-check). */
+enum { HF_ASM_LDS_ATOMIC = 0, HF_ASM_LDS_COLORED = 1, HF_ASM_GLOBAL_ATOMIC = 2 };
+
+/* Kernels addressable by hf_time_kernel */
+enum {
+  HF_K_SPMV = 0,        /* y = A x, CSR, LDS-staged products            */
+  HF_K_PCG_SPMV = 1,    /* Ap = A p with fused p.Ap partial sums        */
+  HF_K_PCG_UPDATE = 2,  /* x += a p; r -= a Ap; z = D^-1 r; r.z, z.z    */
+  HF_K_PCG_DIR = 3,     /* p = z + b p                                  */
+  HF_K_ASSEMBLE = 4,    /* element kernel in the mode of the last hf_assemble */
+  HF_K_RHS = 5          /* b = M u^n                                    */
+};
+
+const char* hf_version(void);
+
+int hf_create(int device_id, hf_ctx** out);
+int hf_destroy(hf_ctx* ctx);
+const char* hf_last_error(const hf_ctx* ctx);
+
+/* Mesh: n nodes, n_e P1 triangles.  zr = n x 2 (z, r); tri = n_e x 3 node ids;
+ * tag = n_e cell tags (>= 0).  Builds the CSR sparsity pattern and the row-block
+ * element lists once (host side) and uploads everything. */
+int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t n_e, const double* zr, const int32_t* tri, const int32_t* tag);
+
+/* Cell-tag -> coefficient tables: kappa[c] = kappa[i], rho_c[c] = rho_c[i] for cells with
+ * tag == tags[i].  May be called again (kappa sweep) followed by hf_assemble. */
+int hf_set_materials(hf_ctx* ctx, int32_t n_mat, const int32_t* tags, const double* kappa, const double* rho_c);
+
+/* Dirichlet DOFs (unique; the host resolves overlaps "later BC wins" beforehand).
+ * The order defines the order of g_bc in hf_step.  n_bc = 0 removes all BCs. */
+int hf_set_dirichlet(hf_ctx* ctx, int32_t n_bc, const int32_t* dofs);
+
+/* M = M_r(rho_c), A = M + dt K_r(kappa); then rows+columns of the Dirichlet DOFs are
+ * zeroed with unit diagonal (the lifting columns are kept aside) and D^-1 is formed. */
+int hf_assemble(hf_ctx* ctx, double dt, int32_t mode);
+
+int hf_set_state(hf_ctx* ctx, const double* u);
+int hf_get_state(hf_ctx* ctx, double* u);
+int hf_sample(hf_ctx* ctx, int32_t n_s, const int32_t* nodes, double* out);
+
+/* One backward-Euler step: b = M u^n - A[:,B] g, b_B = g, solve A_hat u^{n+1} = b by
+ * Jacobi-PCG started from u^n (with u_B = g), in place.  Stops when
+ * ||D^-1 r||_2 <= max(rtol * ||D^-1 b||_2, atol).  iters / resid (relative) may be NULL. */
+int hf_step(hf_ctx* ctx, const double* g_bc, double rtol, double atol, int32_t max_it, int32_t* iters, double* resid);
+
+/* n_steps steps in one call: g_bc_all = n_steps x n_bc; after every step the n_s nodes
+ * are sampled into samples (n_steps x n_s).  iters = n_steps entries (may be NULL). */
+int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_bc_all, double rtol, double atol, int32_t max_it,
+           int32_t n_s, const int32_t* nodes, double* samples, int32_t* iters);
+
+int hf_get_sizes(hf_ctx* ctx, int32_t* n, int32_t* n_e, int64_t* nnz, int32_t* n_bc);
+/* Any pointer may be NULL.  A is the matrix as it stands (eliminated when BCs are set). */
+int hf_get_csr(hf_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* A, double* M);
+/* y = A x (which = 0) or y = M x (which = 1) through the SpMV kernel; host vectors. */
+int hf_spmv(hf_ctx* ctx, int32_t which, const double* x, double* y);
+
+/* Average duration (ms) of `reps` back-to-back launches of one kernel on the ctx stream,
+ * bracketed by HIP events on that stream. */
+int hf_time_kernel(hf_ctx* ctx, int32_t which, int32_t reps, double* ms_avg);
+/* GPU time (ms, HIP events on the ctx stream) of the last hf_step / hf_run / hf_assemble. */
+int hf_last_gpu_ms(hf_ctx* ctx, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEATFLOW_HIP_H */

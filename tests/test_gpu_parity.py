@@ -1,0 +1,201 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances (float64):
+  * matrix entries (M, A, A_hat)          relative 1e-13 of the row's largest entry
+  * SpMV                                   relative 1e-14 (products are summed in CSR order)
+  * temperature field, every time step     |T_hip - T_oracle| <= 1e-4 K  (fields are 300..2700 K,
+    i.e. ~4e-8 relative; measured ~3e-6 K at the default PCG rtol = 1e-10)
+"""
+import numpy as np
+import pytest
+
+from helpers import csr_values_on_pattern, make_problem, material_tables, oracle_run, reference_bcs
+
+pytestmark = pytest.mark.gpu
+
+FIELD_TOL_K = 1e-4
+
+
+def _rel_row_err(dev, ref, rowptr):
+    scale = np.maximum.reduceat(np.abs(ref), rowptr[:-1])
+    rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+    return np.max(np.abs(dev - ref) / scale[rows])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("case", ["with_diamond", "no_diamond"])
+def test_assembly_matches_oracle(hip, case, mode, case_with_diamond_small, case_no_diamond_small):
+    from oracle import heat_oracle as ho
+
+    cfg, stack, mesh = case_with_diamond_small if case == "with_diamond" else case_no_diamond_small
+    tag_to_k, tag_to_rc = material_tables(stack, mesh)
+    dt = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
+    with hip.HeatflowHIP(0) as be:
+        be.set_mesh(mesh.coords, mesh.tris, mesh.tags)
+        tags = sorted(tag_to_k)
+        be.set_materials(tags, [tag_to_k[t] for t in tags], [tag_to_rc[t] for t in tags])
+        be.assemble(dt, mode)
+        rowptr, colidx, A, M = be.get_csr()
+    kappa, rho_c = ho.cell_coefficients(mesh.tags, tag_to_k, tag_to_rc)
+    Me, Ke = ho.element_matrices(mesh.coords, mesh.tris.astype(np.int64), rho_c, kappa)
+    M_ref = ho.assemble_csr(len(mesh.coords), mesh.tris.astype(np.int64), Me)
+    A_ref = ho.assemble_csr(len(mesh.coords), mesh.tris.astype(np.int64), Me + dt * Ke)
+    # same pattern
+    assert np.array_equal(rowptr, M_ref.indptr) and np.array_equal(colidx, M_ref.indices)
+    assert _rel_row_err(M, M_ref.data, rowptr) < 1e-13
+    assert _rel_row_err(A, A_ref.data, rowptr) < 1e-13
+    # symmetry is exact: both triangle contributions commute
+    import scipy.sparse as sp
+    Ad = sp.csr_matrix((A, colidx, rowptr))
+    assert abs(Ad - Ad.T).max() == 0.0
+
+
+def test_colored_assembly_is_bitwise_reproducible(hip, case_with_diamond_small):
+    cfg, stack, mesh = case_with_diamond_small
+    tag_to_k, tag_to_rc = material_tables(stack, mesh)
+    tags = sorted(tag_to_k)
+    out = []
+    for _ in range(2):
+        with hip.HeatflowHIP(0) as be:
+            be.set_mesh(mesh.coords, mesh.tris, mesh.tags)
+            be.set_materials(tags, [tag_to_k[t] for t in tags], [tag_to_rc[t] for t in tags])
+            be.assemble(1e-7, hip.ASM_LDS_COLORED)
+            out.append(be.get_csr())
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+
+
+def test_dirichlet_elimination_and_spmv(hip, case_no_diamond_small):
+    from oracle import heat_oracle as ho
+
+    cfg, stack, mesh = case_no_diamond_small
+    prob = make_problem(cfg, stack, mesh)
+    try:
+        res = oracle_run(cfg, mesh, 0)
+        sol = res["solver"]
+        assert np.array_equal(prob.bc_dofs, sol.bc_dofs)
+        rowptr, colidx, A, M = prob.backend.get_csr()
+        Ahat_ref = csr_values_on_pattern(sol.Ahat, rowptr, colidx)
+        assert _rel_row_err(A, Ahat_ref, rowptr) < 1e-13
+        assert _rel_row_err(M, sol.M.data, rowptr) < 1e-13
+        rng = np.random.default_rng(7)
+        x = rng.standard_normal(len(mesh.coords))
+        import scipy.sparse as sp
+        Ad = sp.csr_matrix((A, colidx, rowptr))
+        y_ref = Ad @ x
+        y = prob.backend.spmv(x, 0)
+        assert np.max(np.abs(y - y_ref)) <= 1e-14 * np.max(np.abs(y_ref))
+        Md = sp.csr_matrix((M, colidx, rowptr))
+        assert np.max(np.abs(prob.backend.spmv(x, 1) - Md @ x)) <= 1e-14 * np.max(np.abs(Md @ x))
+    finally:
+        prob.close()
+
+
+@pytest.mark.parametrize("case", ["with_diamond", "no_diamond"])
+def test_time_loop_matches_oracle_every_step(hip, case, case_with_diamond_small, case_no_diamond_small):
+    cfg, stack, mesh = case_with_diamond_small if case == "with_diamond" else case_no_diamond_small
+    nsteps = 16
+    ref = oracle_run(cfg, mesh, nsteps)
+    prob = make_problem(cfg, stack, mesh)
+    try:
+        for bc in prob.bcs:
+            bc.update(0.0)
+        worst = 0.0
+        for k in range(nsteps):
+            t = (k + 1) * prob.dt
+            it, res = prob.step(t, only=[prob.bcs[3]])
+            u = prob.state()
+            err = np.max(np.abs(u - ref["fields"][k]))
+            worst = max(worst, err)
+            assert err <= FIELD_TOL_K, f"step {k}: |dT| = {err:.3e} K after {it} iterations"
+        # the heated steps must really have been solved iteratively
+        assert max(prob.iters) > 10
+        assert ref["fields"][-1].max() > 400.0
+        print(f"{case}: worst |dT| = {worst:.3e} K, iterations/step = {prob.iters}")
+    finally:
+        prob.close()
+
+
+def test_run_batch_equals_stepwise_and_watchers(hip, case_with_diamond_small):
+    from heatflow_amd.geometry import watcher_points
+    from heatflow_amd.solver import nearest_nodes
+
+    cfg, stack, mesh = case_with_diamond_small
+    wp = watcher_points(cfg)
+    nodes = nearest_nodes(mesh.coords, list(wp.values()))
+    nsteps = 12
+    ref = oracle_run(cfg, mesh, nsteps, keep_fields=False, watcher_nodes=nodes)
+    prob = make_problem(cfg, stack, mesh)
+    try:
+        times, samples, iters = prob.run(nsteps, watcher_nodes=nodes, time_varying=[prob.bcs[3]])
+        assert np.allclose(times, ref["times"], rtol=0, atol=1e-20)
+        assert np.max(np.abs(samples - ref["watchers"])) <= FIELD_TOL_K
+        assert len(iters) == nsteps
+    finally:
+        prob.close()
+
+
+def test_constant_field_is_preserved_before_heating_starts(hip, case_with_diamond_small):
+    """For t < 3.566e-7 s every BC value is ic_temp, so u stays 300 (K 1 = 0, A 1 = M 1)."""
+    cfg, stack, mesh = case_with_diamond_small
+    prob = make_problem(cfg, stack, mesh)
+    try:
+        for bc in prob.bcs:
+            bc.update(0.0)
+        for k in range(4):
+            it, _ = prob.step((k + 1) * prob.dt)
+            assert it == 0
+            assert np.max(np.abs(prob.state() - 300.0)) < 1e-9
+    finally:
+        prob.close()
+
+
+def test_kappa_update_reuses_pattern(hip, case_with_diamond_small):
+    cfg, stack, mesh = case_with_diamond_small
+    import copy
+    prob = make_problem(cfg, stack, mesh)
+    try:
+        tag_to_k, tag_to_rc = material_tables(stack, mesh)
+        tag_to_k = dict(tag_to_k)
+        tag_to_k[mesh.material_tags["p_sample"]] = 4.4
+        prob.set_materials(tag_to_k, tag_to_rc)
+        cfg2 = copy.deepcopy(cfg)
+        cfg2["mats"]["p_sample"]["k"] = 4.4
+        ref = oracle_run(cfg2, mesh, 10)
+        for bc in prob.bcs:
+            bc.update(0.0)
+        for k in range(10):
+            prob.step((k + 1) * prob.dt)
+        assert np.max(np.abs(prob.state() - ref["fields"][-1])) <= FIELD_TOL_K
+    finally:
+        prob.close()
+
+
+def test_error_behaviour(hip, case_no_diamond_small):
+    cfg, stack, mesh = case_no_diamond_small
+    with hip.HeatflowHIP(0) as be:
+        with pytest.raises(hip.HipError):
+            be.assemble(1e-7, 0)                      # no mesh yet
+        bad = mesh.tris.copy()
+        bad[0, 0] = len(mesh.coords) + 5
+        with pytest.raises(ValueError):
+            be.set_mesh(mesh.coords, bad, mesh.tags)   # index out of range is caught on the host
+        be.set_mesh(mesh.coords, mesh.tris, mesh.tags)
+        with pytest.raises(ValueError):
+            be.set_materials([1], [1.0], [1.0])        # tags 2..5 unmapped
+        with pytest.raises(ValueError):
+            be.set_dirichlet([0, 0])                   # duplicates must be resolved by the caller
+        with pytest.raises(hip.HipError):
+            be.step(np.zeros(0))                       # not assembled
+
+
+def test_not_converged_is_reported(hip, case_no_diamond_small):
+    cfg, stack, mesh = case_no_diamond_small
+    prob = make_problem(cfg, stack, mesh, max_it=4)
+    try:
+        for bc in prob.bcs:
+            bc.update(0.0)
+        with pytest.raises(hip.NotConverged):
+            for k in range(8):
+                prob.step((k + 1) * prob.dt)
+    finally:
+        prob.close()
