@@ -87,6 +87,12 @@ struct hf_ctx {
   double* d_samp = nullptr;
   int samp_cap = 0;
   int pred_iters = 0;
+  // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
+  bool prof = false;
+  std::vector<hipEvent_t> prof_ev;
+  int prof_used = 0, prof_base = 0;
+  double prof_spmv_ms = 0.0;
+  long long prof_spmv_n = 0;
 };
 
 namespace {
@@ -608,8 +614,13 @@ void launch_spmv(hf_ctx* c, const double* vals, const double* x, double* y, doub
                      c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, c->d_dinv, pvec, part1, part2);
 }
 
+constexpr int PROF_PAIRS = 64;
+
 void launch_pcg_iteration(hf_ctx* c, int parity) {
+  const bool timed = c->prof && c->prof_used < PROF_PAIRS;
+  if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_used], c->stream);
   launch_spmv<1>(c, c->d_A, c->d_p, c->d_Ap, c->d_part_pAp);
+  if (timed) { (void)hipEventRecord(c->prof_ev[2 * c->prof_used + 1], c->stream); c->prof_used++; }
   hipLaunchKernelGGL(k_pcg_update, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
                      c->d_part_pAp, c->d_part_rz, c->d_part_zz, c->d_u, c->d_r, c->d_p, c->d_Ap, c->d_dinv);
   hipLaunchKernelGGL(k_pcg_dir, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
@@ -619,6 +630,17 @@ void launch_pcg_iteration(hf_ctx* c, int parity) {
 int read_scal(hf_ctx* ctx) {
   HF_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
   HF_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->prof) {  // harvest the event pairs of this burst (only launches that really ran count)
+    for (int k = 0; k < ctx->prof_used; ++k) {
+      float ms = 0.f;
+      const bool ran = !ctx->h_scal->done || (ctx->prof_base + k) < ctx->h_scal->iters;
+      if (ran && hipEventElapsedTime(&ms, ctx->prof_ev[2 * k], ctx->prof_ev[2 * k + 1]) == hipSuccess) {
+        ctx->prof_spmv_ms += ms;
+        ctx->prof_spmv_n += 1;
+      }
+    }
+    ctx->prof_used = 0;
+  }
   return HF_OK;
 }
 
@@ -651,6 +673,7 @@ int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
   int burst = std::max(2, std::min(max_it, ctx->pred_iters > 0 ? ctx->pred_iters : 32));
   while (true) {
     burst += burst & 1;  // parity pairs
+    ctx->prof_base = launched;
     for (int k = 0; k < burst; ++k) launch_pcg_iteration(ctx, (launched + k) & 1);
     launched += burst;
     HF_HIP(hipGetLastError());
@@ -767,6 +790,7 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_u); dev_free(&ctx->d_b); dev_free(&ctx->d_r); dev_free(&ctx->d_p); dev_free(&ctx->d_Ap);
   dev_free(&ctx->d_tmp); dev_free(&ctx->d_part_pAp); dev_free(&ctx->d_part_rz); dev_free(&ctx->d_part_zz);
   dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp);
+  for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1089,6 +1113,27 @@ int hf_time_kernel(hf_ctx* ctx, int32_t which, int32_t reps, double* ms_avg) {
     }
   }
   if (which == HF_K_ASSEMBLE) ctx->assembled = false;  // BC elimination was undone: caller re-assembles
+  return HF_OK;
+}
+
+int hf_set_profile(hf_ctx* ctx, int32_t on) {
+  if (!ctx) return HF_ERR_ARG;
+  HF_HIP(hipSetDevice(ctx->dev));
+  if (on && ctx->prof_ev.empty()) {
+    ctx->prof_ev.resize(2 * PROF_PAIRS);
+    for (auto& e : ctx->prof_ev) HF_HIP(hipEventCreate(&e));
+  }
+  ctx->prof = on != 0;
+  ctx->prof_used = 0;
+  ctx->prof_spmv_ms = 0.0;
+  ctx->prof_spmv_n = 0;
+  return HF_OK;
+}
+
+int hf_get_profile(hf_ctx* ctx, double* spmv_ms_sum, int64_t* spmv_launches) {
+  if (!ctx || !spmv_ms_sum || !spmv_launches) return HF_ERR_ARG;
+  *spmv_ms_sum = ctx->prof_spmv_ms;
+  *spmv_launches = ctx->prof_spmv_n;
   return HF_OK;
 }
 

@@ -21,7 +21,7 @@ K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS = range(6)
 EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_materials",
     "hf_set_dirichlet", "hf_assemble", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
-    "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_last_gpu_ms",
+    "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
 
 
@@ -92,6 +92,8 @@ def load_library():
         "hf_spmv": [vp, i32, pd, pd],
         "hf_time_kernel": [vp, i32, i32, pd],
         "hf_last_gpu_ms": [vp, pd],
+        "hf_set_profile": [vp, i32],
+        "hf_get_profile": [vp, pd, C.POINTER(i64)],
     }
     for name, args in protos.items():
         fn = getattr(lib, name)
@@ -251,6 +253,15 @@ class HeatflowHIP:
         ms = C.c_double()
         self._check(self._lib.hf_time_kernel(self._ctx, int(which), int(reps), C.byref(ms)))
         return ms.value
+
+    def set_profile(self, on=True):
+        self._check(self._lib.hf_set_profile(self._ctx, 1 if on else 0))
+
+    def get_profile(self):
+        """(summed ms, launches) of the PCG SpMV launches bracketed since set_profile(True)."""
+        ms, cnt = C.c_double(), C.c_int64()
+        self._check(self._lib.hf_get_profile(self._ctx, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
 
     def last_gpu_ms(self):
         ms = C.c_double()

@@ -109,7 +109,7 @@ def test_time_loop_matches_oracle_every_step(hip, case, case_with_diamond_small,
             assert err <= FIELD_TOL_K, f"step {k}: |dT| = {err:.3e} K after {it} iterations"
         # the heated steps must really have been solved iteratively
         assert max(prob.iters) > 10
-        assert ref["fields"][-1].max() > 400.0
+        assert ref["fields"][-1].max() > 310.0
         print(f"{case}: worst |dT| = {worst:.3e} K, iterations/step = {prob.iters}")
     finally:
         prob.close()
