@@ -1,0 +1,298 @@
+"""Shared implementation of the ``run_simulation`` entry points.
+
+``run_with_diamond.run_simulation`` / ``run_no_diamond.run_simulation`` keep the reference
+signature (run_with_diamond.py:27, run_no_diamond.py:29):
+
+    run_simulation(cfg, mesh_folder, rebuild_mesh=False, visualize_mesh=False,
+                   output_folder=None, watcher_points=None, write_xdmf=True, suppress_print=False)
+
+and the same side effects: mesh cache ``<mesh_folder>/mesh.msh`` + ``mesh_cfg.yaml`` (cfg copy
+plus ``material_tags``, :194-230), ``<out>/used_config.yaml`` (:403-404), ``<out>/watcher_points.csv``
+with columns ``time,<watcher names>`` (:510-515), default output folder
+``sim_outputs/refactor_test`` (:405-409), ``FileNotFoundError`` when the cache is missing
+(:219-226), ``ValueError`` for a bad ``watcher_points`` (:439) or heating CSV (:268-271),
+``RuntimeError("No DOFs found ...")`` from the BC location (bc.py:105-106).
+
+What differs by design: the mesh comes from heatflow_amd.mesh (no gmsh), assembly and the time
+loop run on the GPU through libheatflow_hip.so, and a :class:`SimulationSession` keeps mesh,
+sparsity pattern and mass matrix resident so a sweep re-values only what changed.
+"""
+from __future__ import annotations
+
+import contextlib
+import copy
+import csv
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import yaml
+
+from .bc import P1Space, RowDirichletBC
+from .geometry import stack_no_diamond, stack_with_diamond
+from .heating import HeatingCurve
+from .mesh import Mesh, load_mesh_arrays
+from .solver import DEFAULT_MAX_IT, DEFAULT_RTOL, HeatProblem, nearest_nodes
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@contextlib.contextmanager
+def suppress_output(enabled):
+    """Redirect stdout/stderr to devnull while ``enabled`` (reference run_with_diamond.py:18-25)."""
+    if not enabled:
+        yield
+        return
+    with open(os.devnull, "w") as sink, contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+        yield
+
+
+def _resolve(path):
+    """Heating file paths in the cfgs are relative to the repository root (cwd in the reference)."""
+    if os.path.isabs(path) or os.path.isfile(path):
+        return path
+    alt = os.path.join(_PKG_ROOT, path)
+    return alt if os.path.isfile(alt) else path
+
+
+def _parse_watchers(watcher_points):
+    if watcher_points is None:
+        return [], []
+    if isinstance(watcher_points, dict):
+        return list(watcher_points.keys()), [tuple(v) for v in watcher_points.values()]
+    if isinstance(watcher_points, list):
+        return [pt["name"] for pt in watcher_points], [tuple(pt["coords"]) for pt in watcher_points]
+    raise ValueError("watcher_points must be a dict or list of dicts")
+
+
+def prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack):
+    """Build-and-cache or load the mesh.  Returns (coords, tris, tags, material_tags)."""
+    mesh_cfg_path = os.path.join(mesh_folder, "mesh_cfg.yaml")
+    mesh_file_path = os.path.join(mesh_folder, "mesh.msh")
+    if rebuild_mesh:
+        mesh = Mesh(name="mesh.msh", boundaries=stack.bounds, materials=stack.materials)
+        mesh.build_mesh()
+        tag_map = {m.name: int(getattr(m, "_tag", -1)) for m in stack.materials}
+        os.makedirs(mesh_folder, exist_ok=True)
+        mesh_cfg = copy.deepcopy(cfg)
+        mesh_cfg["material_tags"] = tag_map
+        with open(mesh_cfg_path, "w") as f:
+            yaml.safe_dump(mesh_cfg, f)
+        mesh.write(mesh_file_path)
+        return mesh.coords, mesh.tris, mesh.tags, tag_map
+    missing = [nm for nm, p in (("mesh.msh", mesh_file_path), ("mesh_cfg.yaml", mesh_cfg_path)) if not os.path.isfile(p)]
+    if missing:
+        raise FileNotFoundError(f"Missing required file(s) in {mesh_folder}: {', '.join(missing)}")
+    with open(mesh_cfg_path) as f:
+        mesh_cfg = yaml.safe_load(f)
+    tag_map = mesh_cfg["material_tags"]
+    coords, tris, tags = load_mesh_arrays(mesh_file_path)
+    return coords, tris, tags, tag_map
+
+
+class SimulationSession:
+    """A mesh resident on one GPU, reusable for many runs of the same geometry.
+
+    ``run(cfg, ...)`` re-values the coefficient tables / matrices only when they differ from
+    the previous run and re-tabulates the boundary values (fwhm, heating curve) on the host.
+    """
+
+    def __init__(self, coords, tris, tags, material_tags, *, device_id=0, backend=None, rtol=DEFAULT_RTOL,
+                 max_it=DEFAULT_MAX_IT, assembly_mode=0):
+        self.coords = np.ascontiguousarray(coords, dtype=np.float64)
+        self.tris = np.ascontiguousarray(tris, dtype=np.int32)
+        self.tags = np.ascontiguousarray(tags, dtype=np.int32)
+        self.material_tags = dict(material_tags)
+        self.device_id, self.backend = device_id, backend
+        self.rtol, self.max_it, self.assembly_mode = rtol, max_it, assembly_mode
+        self.problem = None
+        self._key = None
+
+    def close(self):
+        if self.problem is not None:
+            self.problem.close()
+            self.problem = None
+
+    def _tables(self, stack):
+        tag_to_k = {self.material_tags[m.name]: m.properties["k"] for m in stack.materials}
+        tag_to_rc = {self.material_tags[m.name]: m.properties["rho_cv"] for m in stack.materials}
+        return tag_to_k, tag_to_rc
+
+    def run(self, cfg, stack, watcher_points=None, field_sink=None):
+        """One simulation (reference loop run_with_diamond.py:456-504).  Returns a dict with
+        ``times``, ``watchers`` {name: array}, ``iters``, timing numbers."""
+        t_start = time.time()
+        t_final = float(cfg["timing"]["t_final"])
+        num_steps = int(cfg["timing"]["num_steps"])
+        dt = t_final / num_steps
+        ic_temp = float(cfg["heating"]["ic_temp"])
+        heat = HeatingCurve(_resolve(cfg["heating"]["file"]), ic_temp, float(cfg["heating"]["fwhm"]))
+
+        V = P1Space(self.coords)
+        bcs = [
+            RowDirichletBC(V, "left", value=ic_temp),
+            RowDirichletBC(V, "right", value=ic_temp),
+            RowDirichletBC(V, "top", value=ic_temp),      # named bottom_bc in the reference, location 'top'
+            RowDirichletBC(V, "x", coord=stack.heated_z, length=abs(stack.r_sample) * 2, center=0.0,
+                           value=heat.gaussian),
+        ]
+        tag_to_k, tag_to_rc = self._tables(stack)
+        key = (dt, tuple(sorted(tag_to_rc.items())), tuple(int(b.row_dofs.sum()) for b in bcs))
+        if self.problem is None or key != self._key:
+            self.close()
+            print("Assigning material properties...")
+            self.problem = HeatProblem(self.coords, self.tris, self.tags, tag_to_k, tag_to_rc, dt, bcs, ic_temp,
+                                       backend=self.backend, device_id=self.device_id, rtol=self.rtol,
+                                       max_it=self.max_it, assembly_mode=self.assembly_mode)
+            self._key = key
+            self._k = dict(tag_to_k)
+            print("Material properties assigned.")
+        else:
+            self.problem.bcs = bcs
+            if tag_to_k != self._k:
+                self.problem.set_materials(tag_to_k, tag_to_rc)   # re-value A on the resident pattern
+                self._k = dict(tag_to_k)
+            self.problem.set_state(ic_temp)
+            self.problem.iters = []
+        prob = self.problem
+
+        names, coords_w = _parse_watchers(watcher_points)
+        nodes = nearest_nodes(self.coords, coords_w) if names else None
+
+        print("Beginning loop...")
+        t_loop = time.time()
+        if field_sink is None:
+            times, samples, iters = prob.run(num_steps, watcher_nodes=nodes, time_varying=[bcs[3]])
+        else:  # step-wise so that every field can be handed to the sink (visualisation output)
+            for bc in bcs:
+                bc.update(0.0)
+            times, rows, iters = [], [], []
+            for step in range(num_steps):
+                t = (step + 1) * dt
+                it, _ = prob.step(t, only=[bcs[3]])
+                u = prob.state()
+                field_sink(t, u)
+                times.append(t)
+                iters.append(it)
+                rows.append(u[nodes] if nodes is not None else np.zeros(0))
+            times, samples, iters = np.array(times), np.array(rows), np.array(iters)
+        loop_time = time.time() - t_loop
+        print(f"Simulation progress: 100% (step {num_steps}/{num_steps}) | Avg time/step: {loop_time / num_steps:.4f} s"
+              f" | PCG iterations/step: mean {np.mean(iters):.0f}, max {int(np.max(iters))}")
+        return {
+            "times": np.asarray(times), "watcher_names": names,
+            "watchers": {nm: samples[:, k] for k, nm in enumerate(names)},
+            "iters": np.asarray(iters), "loop_time": loop_time, "startup_time": t_loop - t_start,
+            "n_dof": prob.n, "dt": dt,
+        }
+
+
+def write_watcher_csv(path, times, names, watchers):
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["time"] + list(names))
+        for k, t in enumerate(times):
+            w.writerow([repr(float(t))] + [repr(float(watchers[nm][k])) for nm in names])
+
+
+class _FieldWriter:
+    """Stand-in for the XDMF time series (reference :414-424, :483-484; h5py is not available):
+    ``output_fields.f64`` (raw float64, one field per step, initial state first) +
+    ``output_fields.json`` (times, n) + ``output_mesh.npz``."""
+
+    def __init__(self, folder, coords, tris, tags):
+        self.path = os.path.join(folder, "output_fields.f64")
+        self.meta = os.path.join(folder, "output_fields.json")
+        np.savez(os.path.join(folder, "output_mesh.npz"), coords=coords, tris=tris, tags=tags)
+        self.f = open(self.path, "wb")
+        self.times = []
+        self.n = len(coords)
+
+    def __call__(self, t, u):
+        np.asarray(u, dtype=np.float64).tofile(self.f)
+        self.times.append(float(t))
+
+    def close(self):
+        self.f.close()
+        with open(self.meta, "w") as f:
+            json.dump({"name": "Temperature (K)", "n": self.n, "times": self.times, "dtype": "float64"}, f)
+
+
+def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_mesh=False, output_folder=None,
+                        watcher_points=None, write_xdmf=True, suppress_print=False, *, device_id=0, backend=None,
+                        session=None, rtol=DEFAULT_RTOL, max_it=DEFAULT_MAX_IT):
+    with suppress_output(suppress_print):
+        program_start = time.time()
+        stack = stack_with_diamond(cfg) if kind == "with_diamond" else stack_no_diamond(cfg)
+        own_session = session is None
+        if own_session:
+            coords, tris, tags, tag_map = prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack)
+            session = SimulationSession(coords, tris, tags, tag_map, device_id=device_id, backend=backend, rtol=rtol,
+                                        max_it=max_it)
+        if visualize_mesh:
+            print("visualize_mesh: the gmsh GUI is not part of this build; open mesh.msh in gmsh instead.")
+        _parse_watchers(watcher_points)  # validate before any work, as the reference does at :431-439
+
+        if output_folder is not None:
+            save_folder = output_folder
+            os.makedirs(save_folder, exist_ok=True)
+            with open(os.path.join(save_folder, "used_config.yaml"), "w") as f:
+                yaml.safe_dump(cfg, f)
+        else:
+            save_folder = os.path.join(os.getcwd(), "sim_outputs", "refactor_test")
+            os.makedirs(save_folder, exist_ok=True)
+
+        sink = _FieldWriter(save_folder, session.coords, session.tris, session.tags) if write_xdmf else None
+        try:
+            if sink is not None:
+                sink(0.0, np.full(len(session.coords), float(cfg["heating"]["ic_temp"])))
+            result = session.run(cfg, stack, watcher_points, field_sink=sink)
+        finally:
+            if sink is not None:
+                sink.close()
+            if own_session:
+                session.close()
+
+        if watcher_points is not None:
+            write_watcher_csv(os.path.join(save_folder, "watcher_points.csv"), result["times"], result["watcher_names"],
+                              result["watchers"])
+        total = time.time() - program_start
+        n_steps = len(result["times"])
+        print("\n--- Timing Summary ---")
+        print(f"Total time: {total:.2f} s")
+        print(f"Startup time: {total - result['loop_time']:.2f} s")
+        print(f"Loop time: {result['loop_time']:.2f} s")
+        print(f"Average time per step: {result['loop_time'] / max(n_steps, 1):.4f} s")
+        print("----------------------\n")
+        result["save_folder"] = save_folder
+        result["total_time"] = total
+        return result
+
+
+def cli(kind, argv=None):
+    """Command line of the drivers.  (The reference's own CLI cannot start: argparse is given
+    ``type='dict'``, run_with_diamond.py:540; ``--watcher-points`` takes JSON here.)"""
+    import argparse
+
+    p = argparse.ArgumentParser(description="Heatflow simulation runner (MI355X)")
+    p.add_argument("--config", type=str, default="simulation_template.yaml")
+    p.add_argument("--mesh-folder", type=str, default="meshes")
+    p.add_argument("--rebuild-mesh", action="store_true")
+    p.add_argument("--visualize-mesh", action="store_true")
+    p.add_argument("--output-folder", type=str)
+    p.add_argument("--watcher-points", type=json.loads, help='JSON, e.g. {"pside": [z, r]}')
+    p.add_argument("--write-xdmf", action="store_true")
+    p.add_argument("--suppress-print", action="store_true")
+    p.add_argument("--device", type=int, default=0)
+    a = p.parse_args(argv)
+    with open(a.config) as f:
+        cfg = yaml.safe_load(f)
+    run_simulation_impl(kind, cfg, a.mesh_folder, a.rebuild_mesh, a.visualize_mesh, a.output_folder, a.watcher_points,
+                        a.write_xdmf, a.suppress_print, device_id=a.device)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(cli("with_diamond"))

@@ -19,7 +19,8 @@ Method: a 2:1-balanced quadtree over a virtual tensor-product *base grid*
 material break points, so interfaces are grid lines).  A leaf of level L spans
 2^L x 2^L base cells.  Leaves without hanging nodes are cut into 2 right
 triangles; leaves with hanging mid-edge nodes get a centre node and a fan.
-All triangles are right triangles (non-obtuse), nodes and triangles are
+Plain cells give right triangles; fan triangles of the (near-square) graded
+cells keep all angles within ~[30, 120] degrees.  Nodes and triangles are
 numbered along a Morton curve for cache locality of the SpMV gathers.
 
 The quadtree lives in a dense int8 level map over the base cells (20-80 M

@@ -1,0 +1,323 @@
+"""Parameter sweeps, sharded one point per GPU.
+
+Keeps the reference's sweep surface (parameter_sweep.py): ``create_parameter_grid`` (:195-235,
+logspace fwhm x logspace k x linspace width, grouped by width), ``modify_config_for_parameters``
+(:238-266), ``get_mesh_folder_for_width`` (:269-286), ``get_watcher_points`` (:69-120),
+``run_single_simulation`` (:123-192, one status row per point, exceptions become
+``status='failed'`` rows), ``run_parameter_sweep`` (:289-536) with its artefacts
+``sweep_metadata.json``, ``successful_runs.csv``, ``failed_runs.csv`` and one folder per run.
+
+MI355X-first differences:
+* the reference farms points to a ``multiprocessing.Pool`` whose workers each re-read
+  ``mesh.msh``; here every rank (= one GPU, launched by ``torch.distributed.run``) takes the
+  points ``combos[rank::world]`` of a width group, the group's mesh is built once by rank 0 and
+  **broadcast** to the other ranks (RCCL over xGMI with the nccl backend, gloo on CPU), and a
+  :class:`~heatflow_amd.driver.SimulationSession` keeps mesh + CSR pattern + mass matrix
+  resident on the GPU across that rank's points (only kappa / fwhm dependent data is redone);
+* there is no per-time-step communication; status rows are gathered on rank 0 at the end;
+* ``modify_config_for_parameters`` deep-copies (the reference's shallow copy mutates the
+  shared base dict, which is harmless there only because every call overwrites all three keys).
+"""
+from __future__ import annotations
+
+import copy
+import itertools
+import json
+import os
+import time
+from datetime import datetime
+
+import numpy as np
+import yaml
+
+from .driver import SimulationSession, prepare_mesh, run_simulation_impl
+from .geometry import build_stack, watcher_points as _watcher_points
+
+
+def get_watcher_points(cfg):
+    return _watcher_points(cfg)
+
+
+def create_parameter_grid(fwhm_range, k_range, width_range, num_points):
+    num_fwhm, num_k, num_width = num_points
+    fwhm_vals = np.logspace(np.log10(fwhm_range[0]), np.log10(fwhm_range[1]), num_fwhm)
+    k_vals = np.logspace(np.log10(k_range[0]), np.log10(k_range[1]), num_k)
+    width_vals = np.linspace(width_range[0], width_range[1], num_width)
+    combos = [{"fwhm": fwhm, "k": k, "width": width}
+              for width in width_vals for fwhm, k in itertools.product(fwhm_vals, k_vals)]
+    return combos, fwhm_vals, k_vals, width_vals
+
+
+def modify_config_for_parameters(base_config, fwhm, k, width):
+    config = copy.deepcopy(base_config)
+    config["heating"]["fwhm"] = float(fwhm)
+    config["mats"]["p_sample"]["k"] = float(k)
+    config["mats"]["p_sample"]["z"] = float(width)
+    return config
+
+
+def get_mesh_folder_for_width(base_mesh_folder, width):
+    width_str = f"{width:.3e}".replace("+", "").replace("-0", "-")
+    return os.path.join(base_mesh_folder, f"width_{width_str}")
+
+
+def run_name_for(fwhm, k, width):
+    return f"fwhm_{fwhm:.2e}_k_{k:.2f}_width_{width:.2e}".replace("+", "").replace("-0", "-")
+
+
+# -- process group helpers (work without torch.distributed as a world of 1) ------------------
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except ImportError:
+        pass
+    return None
+
+
+def world_info():
+    d = _dist()
+    return (d.get_rank(), d.get_world_size()) if d is not None else (0, 1)
+
+
+def broadcast_mesh(arrays, src=0):
+    """Broadcast (coords f64 (n,2), tris i32 (ne,3), tags i32 (ne,)) from ``src`` to all ranks.
+    With the nccl backend the tensors travel GPU-to-GPU (RCCL over xGMI); with gloo on the host."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return arrays
+    import torch
+
+    on_gpu = d.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    rank = d.get_rank()
+    sizes = torch.tensor([len(arrays[0]), len(arrays[1])] if rank == src else [0, 0], dtype=torch.int64, device=dev)
+    d.broadcast(sizes, src)
+    n, ne = int(sizes[0]), int(sizes[1])
+    shapes = [((n, 2), torch.float64), ((ne, 3), torch.int32), ((ne,), torch.int32)]
+    out = []
+    for k, (shape, dtype) in enumerate(shapes):
+        if rank == src:
+            t = torch.from_numpy(np.ascontiguousarray(arrays[k])).to(dev)
+        else:
+            t = torch.empty(shape, dtype=dtype, device=dev)
+        d.broadcast(t, src)
+        out.append(t.cpu().numpy())
+    return tuple(out)
+
+
+def shard(items, rank, world):
+    """Round-robin shard: item i -> rank i mod world (8 points per GPU for 64 points on 8 GPUs)."""
+    return [(i, it) for i, it in enumerate(items) if i % world == rank]
+
+
+def run_single_simulation(args, session=None, kind=None):
+    """(combo, base_config, mesh_folder, output_dir, write_xdmf, suppress_print, run_id) -> status row."""
+    combo, base_config, mesh_folder, output_dir, write_xdmf, suppress_print, run_id = args
+    fwhm, k, width = combo["fwhm"], combo["k"], combo["width"]
+    run_name = run_name_for(fwhm, k, width)
+    run_output_dir = os.path.join(output_dir, run_name)
+    config = modify_config_for_parameters(base_config, fwhm, k, width)
+    row = {"run_id": run_id, "run_name": run_name, "fwhm": fwhm, "k": k, "width": width,
+           "output_dir": run_output_dir, "runtime": 0.0, "status": "failed", "error": None}
+    try:
+        t0 = time.time()
+        kind = kind or build_stack(config).kind
+        res = run_simulation_impl(kind, config, mesh_folder, False, False, run_output_dir,
+                                  get_watcher_points(config), write_xdmf, suppress_print, session=session)
+        row.update(runtime=time.time() - t0, status="success",
+                   pcg_iters_mean=float(np.mean(res["iters"])), pcg_iters_max=int(np.max(res["iters"])))
+    except Exception as e:  # a failed / non-converged point is a row, never a silent result
+        row.update(error=str(e))
+    return row
+
+
+def run_parameter_sweep(base_config_path, output_dir, fwhm_range, k_range, width_range, num_points,
+                        base_mesh_folder="meshes", write_xdmf=False, suppress_print=True, num_processes=None, *,
+                        session_factory=None, device_id=None):
+    """Sweep driver.  ``num_processes`` is accepted for signature parity; the degree of
+    parallelism is the size of the torch.distributed world (one rank per GPU).
+    ``session_factory(coords, tris, tags, tag_map)`` lets tests substitute the solver session."""
+    rank, world = world_info()
+    with open(base_config_path) as f:
+        base_config = yaml.safe_load(f)
+    combos, fwhm_vals, k_vals, width_vals = create_parameter_grid(fwhm_range, k_range, width_range, num_points)
+    if device_id is None:
+        device_id = int(os.environ.get("LOCAL_RANK", "0"))
+
+    if rank == 0:
+        os.makedirs(output_dir, exist_ok=True)
+        meta = {
+            "base_config": base_config_path, "fwhm_range": list(fwhm_range), "k_range": list(k_range),
+            "width_range": list(width_range), "num_points": list(num_points), "fwhm_values": fwhm_vals.tolist(),
+            "k_values": k_vals.tolist(), "width_values": width_vals.tolist(), "total_runs": len(combos),
+            "num_processes": world, "timestamp": datetime.now().isoformat(),
+            "watcher_points": {
+                "description": "Temperature monitoring points positioned halfway through iridium coupler layers",
+                "locations": {"pside": "Center of p-side iridium coupler (r=0)",
+                              "oside": "Center of o-side iridium coupler (r=0)"},
+                "coordinates": "Relative to mesh geometry, calculated for each parameter combination"},
+        }
+        with open(os.path.join(output_dir, "sweep_metadata.json"), "w") as f:
+            json.dump(meta, f, indent=2)
+        print(f"Starting parameter sweep with {len(combos)} total runs on {world} rank(s)")
+
+    groups = {}
+    for c in combos:
+        groups.setdefault(c["width"], []).append(c)
+
+    rows, done = [], 0
+    for width, group in groups.items():
+        mesh_folder = get_mesh_folder_for_width(base_mesh_folder, width)
+        cfg0 = modify_config_for_parameters(base_config, group[0]["fwhm"], group[0]["k"], width)
+        stack0 = build_stack(cfg0)
+        arrays, tag_map = None, {m.name: k + 1 for k, m in enumerate(stack0.materials)}
+        if rank == 0:
+            have = os.path.exists(os.path.join(mesh_folder, "mesh.msh")) and \
+                os.path.exists(os.path.join(mesh_folder, "mesh_cfg.yaml"))
+            coords, tris, tags, tag_map = prepare_mesh(cfg0, mesh_folder, not have, stack0)
+            arrays = (coords, tris, tags)
+        arrays = broadcast_mesh(arrays if arrays is not None else (np.zeros((0, 2)), np.zeros((0, 3), np.int32),
+                                                                   np.zeros(0, np.int32)))
+        if session_factory is not None:
+            session = session_factory(*arrays, tag_map)
+        else:
+            session = SimulationSession(*arrays, tag_map, device_id=device_id)
+        try:
+            for idx, combo in shard(group, rank, world):
+                row = run_single_simulation((combo, base_config, mesh_folder, output_dir, write_xdmf, suppress_print,
+                                             done + idx + 1), session=session, kind=stack0.kind)
+                row["rank"] = rank
+                rows.append(row)
+        finally:
+            session.close()
+        done += len(group)
+
+    d = _dist()
+    if d is not None and world > 1:
+        gathered = [None] * world
+        d.all_gather_object(gathered, rows)
+        rows = [r for part in gathered for r in part]
+    rows.sort(key=lambda r: r["run_id"])
+    results = [r for r in rows if r["status"] == "success"]
+    failed = [r for r in rows if r["status"] != "success"]
+    if rank == 0:
+        _write_rows(os.path.join(output_dir, "successful_runs.csv"), results)
+        _write_rows(os.path.join(output_dir, "failed_runs.csv"), failed)
+        print(f"PARAMETER SWEEP COMPLETE: total {len(combos)}, successful {len(results)}, failed {len(failed)}")
+    return results, failed
+
+
+def _write_rows(path, rows):
+    if not rows:
+        return
+    import csv
+
+    keys = list(rows[0].keys())
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=keys, extrasaction="ignore")
+        w.writeheader()
+        for r in rows:
+            w.writerow(r)
+
+
+# -- kappa-only sweep on a shared mesh (reference sweep_test.py) ------------------------------
+def get_k_values(k0=3.8, half_width=0.5, step=0.02, count=None):
+    """sweep_test.py:47-52: np.round(np.arange(k0-0.5, k0+0.5+step, step), 4); ``count`` picks an
+    evenly spaced grid of that many values over the same interval instead (64 for BASELINE C5)."""
+    if count is not None:
+        return np.round(np.linspace(k0 - half_width, k0 + half_width, int(count)), 4)
+    return np.round(np.arange(k0 - half_width, k0 + half_width + step, step), 4)
+
+
+def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=False, session_factory=None,
+                    device_id=None, exp_csv=None):
+    """k_sample sweep on one mesh: point i -> rank i mod world; the mesh is broadcast once, each
+    rank keeps it resident and only re-values A per point.  Returns rows [{k, rmse, runtime,...}]
+    (rmse of the normalised o-side watcher against the experiment, sweep_test.py:76-93)."""
+    from .analysis_utils import calculate_rmse
+
+    rank, world = world_info()
+    if device_id is None:
+        device_id = int(os.environ.get("LOCAL_RANK", "0"))
+    stack = build_stack(cfg)
+    arrays, tag_map = None, {m.name: k + 1 for k, m in enumerate(stack.materials)}
+    if rank == 0:
+        coords, tris, tags, tag_map = prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack)
+        arrays = (coords, tris, tags)
+        os.makedirs(output_dir, exist_ok=True)
+    arrays = broadcast_mesh(arrays if arrays is not None else (np.zeros((0, 2)), np.zeros((0, 3), np.int32),
+                                                               np.zeros(0, np.int32)))
+    session = session_factory(*arrays, tag_map) if session_factory else SimulationSession(*arrays, tag_map,
+                                                                                        device_id=device_id)
+    exp = None
+    if exp_csv is not None:
+        exp = np.genfromtxt(exp_csv, delimiter=",", names=True)
+    rows = []
+    try:
+        for idx, k in shard(list(k_values), rank, world):
+            c = copy.deepcopy(cfg)
+            c["mats"]["p_sample"]["k"] = float(k)
+            outdir = os.path.join(output_dir, f"{k:.2f}")
+            t0 = time.time()
+            row = {"k": float(k), "rmse": float("nan"), "runtime": 0.0, "status": "failed", "error": None, "rank": rank}
+            try:
+                res = run_simulation_impl(stack.kind, c, mesh_folder, False, False, outdir, get_watcher_points(c),
+                                          False, True, session=session)
+                row.update(status="success", runtime=time.time() - t0, pcg_iters_mean=float(np.mean(res["iters"])))
+                if exp is not None:
+                    ps, os_ = res["watchers"]["pside"], res["watchers"]["oside"]
+                    span = ps.max() - ps.min()
+                    sim_o = (os_ - os_[0]) / span
+                    ic = float(c["heating"]["ic_temp"])
+                    exp_o = exp["oside"] - exp["oside"][0] + ic
+                    exp_o = (exp_o - exp_o[0]) / (exp["temp"].max() - exp["temp"].min())
+                    row["rmse"] = calculate_rmse(exp["time"], exp_o, res["times"], sim_o)
+            except Exception as e:
+                row.update(error=str(e))
+            rows.append(row)
+    finally:
+        session.close()
+    d = _dist()
+    if d is not None and world > 1:
+        gathered = [None] * world
+        d.all_gather_object(gathered, rows)
+        rows = [r for part in gathered for r in part]
+    rows.sort(key=lambda r: r["k"])
+    if rank == 0:
+        _write_rows(os.path.join(output_dir, "rmse_summary.csv"), rows)
+    return rows
+
+
+def main(argv=None):
+    import argparse
+
+    p = argparse.ArgumentParser(description="Parameter sweep (one point per GPU under torch.distributed.run)")
+    p.add_argument("--config", required=True)
+    p.add_argument("--output-dir", required=True)
+    p.add_argument("--fwhm-range", nargs=2, type=float, required=True)
+    p.add_argument("--k-range", nargs=2, type=float, required=True)
+    p.add_argument("--width-range", nargs=2, type=float, required=True)
+    p.add_argument("--num-points", nargs=3, type=int, required=True)
+    p.add_argument("--mesh-folder", default="meshes")
+    p.add_argument("--write-xdmf", action="store_true")
+    p.add_argument("--verbose", action="store_true")
+    a = p.parse_args(argv)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        import torch.distributed as dist
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl" if use_gpu else "gloo")
+    run_parameter_sweep(a.config, a.output_dir, tuple(a.fwhm_range), tuple(a.k_range), tuple(a.width_range),
+                        tuple(a.num_points), a.mesh_folder, a.write_xdmf, not a.verbose)
+    d = _dist()
+    if d is not None:
+        d.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -62,7 +62,7 @@ def element_matrices(zr, tri, rho_c, kappa):
             if i == j:
                 w = (2.0 * r[:, i] + rsum) / 30.0              # (3 r_i + r_j + r_k)/30
             else:
-                w = (rsum + r[:, i] + r[:, j]) / 60.0          # (2 r_i + 2 r_j + r_k)/60
+                w = (rsum + (r[:, i] + r[:, j])) / 60.0        # (2 r_i + 2 r_j + r_k)/60, symmetric in i,j
             Me[:, i, j] = rho_c * area * w
     return Me, Ke
 

@@ -1,0 +1,77 @@
+"""Oracle-backed stand-in for HeatflowHIP, for CPU-only tests of the host logic (drivers,
+sweeps, sharding).  TEST CODE: it lives under tests/ and is never imported by heatflow_amd."""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from oracle import heat_oracle as ho
+
+
+class OracleBackend:
+    def __init__(self, device_id=0):
+        self.n = self.n_e = self.n_bc = 0
+        self.nnz = 0
+        self.bc_dofs = np.zeros(0, dtype=np.int64)
+        self._lu = None
+        self.closed = False
+        self.assemble_calls = 0
+        self.set_mesh_calls = 0
+
+    def close(self):
+        self.closed = True
+
+    def set_mesh(self, coords, tris, tags):
+        self.coords = np.asarray(coords, dtype=np.float64)
+        self.tris = np.asarray(tris, dtype=np.int64)
+        self.tags = np.asarray(tags)
+        self.n, self.n_e = len(self.coords), len(self.tris)
+        self.u = np.zeros(self.n)
+        self.set_mesh_calls += 1
+
+    def set_materials(self, tags, kappa, rho_c):
+        self.tag_to_k = {int(t): float(k) for t, k in zip(tags, kappa)}
+        self.tag_to_rc = {int(t): float(c) for t, c in zip(tags, rho_c)}
+
+    def set_dirichlet(self, dofs):
+        self.bc_dofs = np.asarray(dofs, dtype=np.int64)
+        self.n_bc = len(self.bc_dofs)
+
+    def assemble(self, dt, mode=0):
+        kappa, rho_c = ho.cell_coefficients(self.tags, self.tag_to_k, self.tag_to_rc)
+        Me, Ke = ho.element_matrices(self.coords, self.tris, rho_c, kappa)
+        self.M = ho.assemble_csr(self.n, self.tris, Me)
+        self.A = ho.assemble_csr(self.n, self.tris, Me + dt * Ke)
+        self.nnz = self.A.nnz
+        self.Ahat = ho.eliminate_dirichlet(self.A, self.bc_dofs) if self.n_bc else self.A
+        self.A_lift = self.A[:, self.bc_dofs].tocsr() if self.n_bc else None
+        self._lu = spla.splu(self.Ahat.tocsc())
+        self.assemble_calls += 1
+
+    def set_state(self, u):
+        self.u = np.array(u, dtype=np.float64).copy()
+
+    def get_state(self):
+        return self.u.copy()
+
+    def sample(self, nodes):
+        return self.u[np.asarray(nodes)].copy()
+
+    def step(self, g, rtol=1e-10, atol=0.0, max_it=20000):
+        b = self.M @ self.u
+        if self.n_bc:
+            b -= self.A_lift @ g
+            b[self.bc_dofs] = g
+        self.u = self._lu.solve(b)
+        return 1, 0.0
+
+    def run(self, g_all, rtol=1e-10, atol=0.0, max_it=20000, nodes=None):
+        ns = 0 if nodes is None else len(nodes)
+        samples = np.empty((len(g_all), ns))
+        for k, g in enumerate(g_all):
+            self.step(g)
+            if ns:
+                samples[k] = self.u[np.asarray(nodes)]
+        return samples, np.ones(len(g_all), dtype=np.int32)
+
+    def last_gpu_ms(self):
+        return 0.0

@@ -1,0 +1,185 @@
+"""Host logic of the entry points and of the sweep sharding, on CPU.  The solver session is
+given an oracle-backed backend (tests/oracle_backend.py) through the injection points; the
+product default (HeatflowHIP) is exercised by the GPU tests."""
+import copy
+import csv
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import yaml
+
+from conftest import ROOT, load_cfg
+from heatflow_amd import parameter_sweep as ps
+from heatflow_amd.geometry import scale_mesh_sizes, watcher_points
+from oracle_backend import OracleBackend
+
+
+def _cfg(name="geballe_with_diamond", scale=16.0, steps=8):
+    cfg = scale_mesh_sizes(load_cfg(name), scale)
+    cfg["timing"]["num_steps"] = steps
+    cfg["timing"]["t_final"] = 7.5e-8 * steps if name == "geballe_with_diamond" else 1.875e-7 * steps
+    return cfg
+
+
+@pytest.mark.parametrize("module,name", [("run_with_diamond", "geballe_with_diamond"), ("run_no_diamond", "geballe_no_diamond")])
+def test_run_simulation_outputs_and_mesh_cache(tmp_path, module, name):
+    import importlib
+
+    run = importlib.import_module(module)            # the root-level drop-in module names
+    cfg = _cfg(name)
+    mesh_folder, out = str(tmp_path / "mesh"), str(tmp_path / "out")
+    with pytest.raises(FileNotFoundError, match="mesh.msh, mesh_cfg.yaml"):
+        run.run_simulation(cfg, mesh_folder, rebuild_mesh=False, backend=OracleBackend())
+    wp = watcher_points(cfg)
+    res = run.run_simulation(cfg, mesh_folder, rebuild_mesh=True, output_folder=out, watcher_points=wp,
+                             write_xdmf=False, suppress_print=True, backend=OracleBackend())
+    assert sorted(os.listdir(mesh_folder)) == ["mesh.msh", "mesh.npz", "mesh_cfg.yaml"]
+    with open(os.path.join(mesh_folder, "mesh_cfg.yaml")) as f:
+        mcfg = yaml.safe_load(f)
+    assert mcfg["material_tags"]["p_ins"] >= 1 and "mats" in mcfg
+    with open(os.path.join(out, "used_config.yaml")) as f:
+        assert yaml.safe_load(f)["timing"]["num_steps"] == 8
+    with open(os.path.join(out, "watcher_points.csv")) as f:
+        rows = list(csv.reader(f))
+    assert rows[0] == ["time", "pside", "oside"] and len(rows) == 9
+    dt = float(cfg["timing"]["t_final"]) / 8
+    assert float(rows[1][0]) == dt and float(rows[8][0]) == 8 * dt
+    assert abs(float(rows[8][1]) - 300.0) > 0.1   # heated (a coarse consistent-mass mesh may undershoot)
+    # second run reuses the cache, a list-of-dicts watcher spec works too, XDMF stand-in is written
+    res2 = run.run_simulation(cfg, mesh_folder, output_folder=out, write_xdmf=True, suppress_print=True,
+                              watcher_points=[{"name": "a", "coords": wp["pside"]}], backend=OracleBackend())
+    assert np.allclose(res2["watchers"]["a"], res["watchers"]["pside"], rtol=0, atol=1e-9)
+    meta = json.load(open(os.path.join(out, "output_fields.json")))
+    assert len(meta["times"]) == 9 and os.path.getsize(os.path.join(out, "output_fields.f64")) == 9 * 8 * meta["n"]
+    with pytest.raises(ValueError, match="watcher_points must be a dict or list of dicts"):
+        run.run_simulation(cfg, mesh_folder, watcher_points=3, backend=OracleBackend())
+
+
+def test_default_backend_fails_loudly_without_gpu(tmp_path):
+    """No silent CPU path: without a device the product entry point raises."""
+    from heatflow_amd import hip_backend
+    import ctypes
+    lib = hip_backend.load_library()
+    ctx = ctypes.c_void_p()
+    if lib.hf_create(0, ctypes.byref(ctx)) == 0:
+        lib.hf_destroy(ctx)
+        pytest.skip("a GPU is present")
+    import run_with_diamond as run
+    with pytest.raises(hip_backend.HipUnavailable):
+        run.run_simulation(_cfg(), str(tmp_path / "m"), rebuild_mesh=True, write_xdmf=False, suppress_print=True)
+
+
+def test_grid_helpers_match_reference_conventions():
+    combos, f, k, w = ps.create_parameter_grid((5e-6, 2e-5), (2.0, 8.0), (1.5e-6, 2.5e-6), (3, 2, 2))
+    assert len(combos) == 12 and np.allclose(f, np.logspace(np.log10(5e-6), np.log10(2e-5), 3))
+    assert [c["width"] for c in combos[:6]] == [w[0]] * 6            # grouped by width
+    base = load_cfg("geballe_no_diamond")
+    snap = copy.deepcopy(base)
+    c = ps.modify_config_for_parameters(base, 1e-5, 4.0, 2e-6)
+    assert c["heating"]["fwhm"] == 1e-5 and c["mats"]["p_sample"]["k"] == 4.0 and c["mats"]["p_sample"]["z"] == 2e-6
+    assert base == snap                                               # base untouched (deep copy)
+    assert ps.get_mesh_folder_for_width("meshes", 1.84e-6) == os.path.join("meshes", "width_1.840e-6")
+    assert ps.run_name_for(1.32e-5, 3.8, 1.84e-6) == "fwhm_1.32e-5_k_3.80_width_1.84e-6"
+    ks = ps.get_k_values()
+    assert len(ks) == 51 and ks[0] == 3.3 and ks[-1] == 4.3
+    assert len(ps.get_k_values(count=64)) == 64
+    assert ps.shard(list("abcdefgh"), 1, 3) == [(1, "b"), (4, "e"), (7, "h")]
+
+
+def _session_factory(coords, tris, tags, tag_map):
+    from heatflow_amd.driver import SimulationSession
+    return SimulationSession(coords, tris, tags, tag_map, backend=OracleBackend())
+
+
+def test_sweep_single_process_writes_artefacts_and_failed_rows(tmp_path):
+    cfg = _cfg("geballe_no_diamond", 16.0, 6)
+    cfg_path = str(tmp_path / "base.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    out = str(tmp_path / "sweep")
+    ok, failed = ps.run_parameter_sweep(cfg_path, out, (8e-6, 2e-5), (3.0, 5.0), (1.84e-6, 1.84e-6), (2, 2, 1),
+                                        base_mesh_folder=str(tmp_path / "meshes"), session_factory=_session_factory)
+    assert len(ok) == 4 and not failed
+    meta = json.load(open(os.path.join(out, "sweep_metadata.json")))
+    assert meta["total_runs"] == 4 and len(meta["k_values"]) == 2
+    rows = list(csv.DictReader(open(os.path.join(out, "successful_runs.csv"))))
+    assert [int(r["run_id"]) for r in rows] == [1, 2, 3, 4] and all(r["status"] == "success" for r in rows)
+    for r in rows:
+        assert os.path.isfile(os.path.join(r["output_dir"], "watcher_points.csv"))
+    # a failing point becomes a row in failed_runs.csv, the others still succeed
+    bad = copy.deepcopy(cfg)
+    bad["heating"]["file"] = "does/not/exist.csv"
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(bad, f)
+    ok, failed = ps.run_parameter_sweep(cfg_path, out + "2", (8e-6, 2e-5), (3.0, 5.0), (1.84e-6, 1.84e-6), (1, 2, 1),
+                                        base_mesh_folder=str(tmp_path / "meshes"), session_factory=_session_factory)
+    assert not ok and len(failed) == 2 and "exist.csv" in failed[0]["error"]
+    assert os.path.isfile(os.path.join(out + "2", "failed_runs.csv"))
+
+
+def test_session_keeps_mesh_resident_across_kappa_points(tmp_path):
+    """Within a width group only the coefficient tables / A are redone: one set_mesh, k assembles."""
+    from heatflow_amd.driver import SimulationSession, prepare_mesh
+    from heatflow_amd.geometry import build_stack
+
+    cfg = _cfg("geballe_with_diamond", 16.0, 5)
+    stack = build_stack(cfg)
+    coords, tris, tags, tag_map = prepare_mesh(cfg, str(tmp_path / "m"), True, stack)
+    be = OracleBackend()
+    sess = SimulationSession(coords, tris, tags, tag_map, backend=be)
+    outs = []
+    for k in (3.3, 3.8, 4.3):
+        c = copy.deepcopy(cfg)
+        c["mats"]["p_sample"]["k"] = k
+        outs.append(sess.run(c, build_stack(c), watcher_points(c))["watchers"]["oside"][-1])
+    assert be.set_mesh_calls == 1 and be.assemble_calls == 3
+    assert outs[0] != outs[2]
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import torch.distributed as dist
+    from heatflow_amd import parameter_sweep as ps
+    from test_driver_sweep_cpu import _session_factory
+    dist.init_process_group("gloo")
+    ok, failed = ps.run_parameter_sweep({cfg!r}, {out!r}, (8e-6, 2e-5), (3.0, 5.0), (1.84e-6, 2.2e-6), (2, 2, 2),
+                                        base_mesh_folder={meshes!r}, session_factory=_session_factory)
+    if dist.get_rank() == 0:
+        json.dump({{"ok": ok, "failed": failed}}, open({res!r}, "w"))
+    dist.destroy_process_group()
+""")
+
+
+def test_sweep_world_size_2_gloo_shards_points_and_broadcasts_the_mesh(tmp_path):
+    """Two ranks (gloo, CPU): rank 0 meshes each width group and broadcasts it, points go
+    i -> i mod 2, rows are gathered on rank 0; results equal the single-process sweep."""
+    cfg = _cfg("geballe_no_diamond", 16.0, 5)
+    cfg_path = str(tmp_path / "base.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    out2, res2 = str(tmp_path / "sweep2"), str(tmp_path / "res2.json")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, cfg=cfg_path, out=out2, meshes=str(tmp_path / "meshes2"), res=res2))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", str(script)]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    got = json.load(open(res2))
+    assert len(got["ok"]) == 8 and not got["failed"]
+    assert sorted(r["rank"] for r in got["ok"]) == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert [r["run_id"] for r in got["ok"]] == list(range(1, 9))
+    out1 = str(tmp_path / "sweep1")
+    ok1, _ = ps.run_parameter_sweep(cfg_path, out1, (8e-6, 2e-5), (3.0, 5.0), (1.84e-6, 2.2e-6), (2, 2, 2),
+                                    base_mesh_folder=str(tmp_path / "meshes1"), session_factory=_session_factory)
+    for a, b in zip(ok1, got["ok"]):
+        assert a["run_name"] == b["run_name"]
+        wa = np.genfromtxt(os.path.join(a["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
+        wb = np.genfromtxt(os.path.join(b["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
+        assert np.array_equal(wa["oside"], wb["oside"]) and np.array_equal(wa["pside"], wb["pside"])

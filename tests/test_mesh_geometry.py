@@ -1,0 +1,156 @@
+"""Host logic: YAML coercions, layer-stack arithmetic, the quadtree mesher, mesh I/O."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+from conftest import ROOT, build_case, load_cfg
+from heatflow_amd.geometry import build_stack, scale_mesh_sizes, stack_no_diamond, stack_with_diamond, watcher_points
+from heatflow_amd.materials import Material
+from heatflow_amd.mesh import Mesh, load_mesh_arrays, read_msh
+
+
+def test_yaml_mantissas_without_a_dot_load_as_strings_and_are_coerced():
+    cfg = load_cfg("geballe_with_diamond")
+    assert isinstance(cfg["mats"]["g_ins"]["r"], str)          # '5e-6' under YAML 1.1
+    assert isinstance(cfg["mats"]["p_coupler"]["z"], float)    # 6.2e-08
+    st = stack_with_diamond(cfg)
+    assert st.by_name("g_ins").boundaries[3] - st.by_name("g_ins").boundaries[2] == pytest.approx(5e-6)
+
+
+def test_with_diamond_boxes():
+    st = stack_with_diamond(load_cfg("geballe_with_diamond"))
+    assert [m.name for m in st.materials] == ["p_diam", "p_ins", "p_coupler", "p_sample", "o_coupler", "o_ins",
+                                              "o_diam", "gasket", "g_ins"]
+    assert st.bounds[0] == pytest.approx(-44.182e-6) and st.bounds[1] == pytest.approx(47.282e-6)
+    assert st.bounds[3] == pytest.approx(80e-6)
+    assert st.heated_z == pytest.approx(-0.982e-6)
+    assert st.heated_z == st.by_name("p_coupler").boundaries[0] == st.by_name("p_ins").boundaries[1]
+    assert st.by_name("p_diam").properties == {"rho_cv": 3500.0 * 510.0, "k": 2000.0}
+    assert st.by_name("gasket").boundaries == pytest.approx([-4.182e-6, 7.282e-6, 25e-6, 80e-6])
+
+
+def test_no_diamond_boxes_and_unmeshed_bound():
+    st = stack_no_diamond(load_cfg("geballe_no_diamond"))
+    assert len(st.materials) == 5
+    assert st.bounds == pytest.approx([-4.182e-6, 7.282e-6, 0.0, 40e-6])   # r_sample + r_ins_oside, not meshed
+    assert max(m.boundaries[3] for m in st.materials) == pytest.approx(20e-6)
+    assert st.heated_z == pytest.approx(-0.982e-6)
+
+
+def test_watcher_points_sit_in_the_coupler_mid_planes():
+    wp = watcher_points(load_cfg("geballe_with_diamond"))
+    assert wp["pside"] == pytest.approx((-0.951e-6, 0.0)) and wp["oside"] == pytest.approx((0.951e-6, 0.0))
+    wp2 = watcher_points(load_cfg("geballe_no_diamond"))
+    assert wp2["pside"][0] == pytest.approx(wp["pside"][0])
+
+
+def test_konopkova_stub_cannot_be_parsed_into_a_run():
+    cfg = load_cfg("konopkova")
+    with pytest.raises((KeyError, ValueError, TypeError)):
+        build_stack(cfg)
+
+
+def test_material_validation_matches_reference():
+    with pytest.raises(TypeError):
+        Material(3, [0, 1, 0, 1])
+    with pytest.raises(ValueError):
+        Material("a", [0, 1, 0])
+    with pytest.raises(ValueError):
+        Material("a", [1, 0, 0, 1])
+    m = Material("a", [0, 1, 0, 2], {"k": 1.0}, 0.1)
+    assert m.contains(0.5, 1.0) and not m.contains(1.5, 1.0)
+
+
+def _edges(tris):
+    e = np.concatenate([tris[:, [0, 1]], tris[:, [1, 2]], tris[:, [2, 0]]])
+    e.sort(axis=1)
+    return e
+
+
+@pytest.mark.parametrize("name,scale", [("geballe_with_diamond", 6.0), ("geballe_no_diamond", 4.0)])
+def test_mesh_is_conforming_tagged_and_sized(name, scale):
+    cfg, st, mesh = build_case(name, scale)
+    c, t = mesh.coords, mesh.tris
+    p0, p1, p2 = c[t[:, 0]], c[t[:, 1]], c[t[:, 2]]
+    area = 0.5 * ((p1[:, 0] - p0[:, 0]) * (p2[:, 1] - p0[:, 1]) - (p2[:, 0] - p0[:, 0]) * (p1[:, 1] - p0[:, 1]))
+    assert (area > 0).all()                                                   # CCW, non-degenerate
+    assert area.sum() == pytest.approx(sum((m.boundaries[1] - m.boundaries[0]) * (m.boundaries[3] - m.boundaries[2])
+                                           for m in st.materials), rel=1e-12)
+    # conforming: every edge is shared by exactly two triangles, or lies on the outer boundary (one)
+    e = _edges(t)
+    uniq, cnt = np.unique(e, axis=0, return_counts=True)
+    assert set(cnt.tolist()) <= {1, 2}
+    bnd = uniq[cnt == 1]
+    zmin, zmax, rmax = c[:, 0].min(), c[:, 0].max(), c[:, 1].max()
+    mid = 0.5 * (c[bnd[:, 0]] + c[bnd[:, 1]])
+    on_hull = np.isclose(mid[:, 0], zmin) | np.isclose(mid[:, 0], zmax) | np.isclose(mid[:, 1], 0.0) | np.isclose(mid[:, 1], rmax)
+    assert on_hull.all()
+    # every node is used
+    assert len(np.unique(t)) == len(c)
+    # tags: triangle centroid inside its material's box; legs no longer than mesh_size
+    cen = (p0 + p1 + p2) / 3
+    for k, m in enumerate(st.materials):
+        sel = mesh.tags == k + 1
+        assert sel.any()
+        b = m.boundaries
+        assert ((cen[sel, 0] > b[0]) & (cen[sel, 0] < b[1]) & (cen[sel, 1] > b[2]) & (cen[sel, 1] < b[3])).all()
+        legs = np.sort(np.stack([np.linalg.norm(p1 - p0, axis=1), np.linalg.norm(p2 - p1, axis=1),
+                                 np.linalg.norm(p0 - p2, axis=1)], axis=1)[sel], axis=1)
+        assert legs[:, 1].max() <= m.mesh_size * (1 + 1e-9)                  # the two legs of the right triangle
+    # shape quality: plain cells give right triangles; fans of (near-square) rectangles stay well
+    # away from degenerate: every angle in [25, 130] degrees
+    def ang(a, b, c_):
+        u, v = b - a, c_ - a
+        cosv = (u * v).sum(1) / np.sqrt((u * u).sum(1) * (v * v).sum(1))
+        return np.degrees(np.arccos(np.clip(cosv, -1, 1)))
+    angles = np.stack([ang(p0, p1, p2), ang(p1, p2, p0), ang(p2, p0, p1)], axis=1)
+    assert angles.min() > 25.0 and angles.max() < 130.0
+    assert np.isclose(angles.max(axis=1), 90.0).mean() > 0.7
+    assert mesh.material_tags == {m.name: k + 1 for k, m in enumerate(st.materials)}
+
+
+def test_stock_no_diamond_has_1001_nodes_on_the_heated_line():
+    """Reference notebooks report 1001 inner-BC DOFs for r in [0, 20 um] at h = 0.02 um."""
+    cfg, st, mesh = build_case("geballe_no_diamond", 1.0)
+    on_line = np.isclose(mesh.coords[:, 0], st.heated_z, atol=1e-10)
+    assert on_line.sum() == 1001
+    assert 1.0e5 < len(mesh.coords) < 2.5e5
+
+
+def test_mesher_is_deterministic_and_grades_into_the_diamond():
+    a = build_case("geballe_with_diamond", 8.0)[2]
+    b = build_case("geballe_with_diamond", 8.0)[2]
+    assert np.array_equal(a.coords, b.coords) and np.array_equal(a.tris, b.tris) and np.array_equal(a.tags, b.tags)
+    assert a.stats["max_level"] >= 5 and a.stats["n_fan_cells"] > 0
+    # far fewer nodes than a tensor grid at the finest spacing would need
+    assert a.stats["n_nodes"] < 0.02 * a.stats["base_grid"][0] * a.stats["base_grid"][1]
+
+
+def test_duplicate_rectangles_are_rejected():
+    m1 = Material("a", [0, 1, 0, 1], {}, 0.5)
+    m2 = Material("b", [0, 1, 0, 1], {}, 0.5)
+    with pytest.raises(RuntimeError):
+        Mesh("m", [0, 2, 0, 2], [m1, m2]).build_mesh()
+
+
+def test_msh_roundtrip(tmp_path):
+    cfg, st, mesh = build_case("geballe_with_diamond", 16.0)
+    path = str(tmp_path / "mesh.msh")
+    mesh.write(path)
+    c1, t1, g1 = load_mesh_arrays(path)                   # npz sidecar
+    c2, t2, g2 = read_msh(path)                           # ASCII MSH 2.2
+    for c, t, g in ((c1, t1, g1), (c2, t2, g2)):
+        assert np.array_equal(c, mesh.coords) and np.array_equal(t, mesh.tris) and np.array_equal(g, mesh.tags)
+    with open(path) as f:
+        head = f.read(200)
+    assert head.startswith("$MeshFormat\n2.2 0 8") and '"p_diam"' in head
+
+
+def test_scale_reaches_one_million_dof_band():
+    """BASELINE C3: one factor on every mesh: value so that n = 1.0e6 +- 5 % (bench.py uses 0.43).
+    Checked through the cell count formula on a cheap proxy: halving h quadruples the nodes."""
+    n1 = build_case("geballe_with_diamond", 4.0)[2].stats["n_nodes"]
+    n2 = build_case("geballe_with_diamond", 2.0)[2].stats["n_nodes"]
+    assert 3.3 < n2 / n1 < 4.3
