@@ -51,7 +51,7 @@ def build_problem_inputs(scale):
     return cfg, stack, mesh
 
 
-def make_problem(cfg, stack, coords, tris, tags, material_tags, k_sample, device_id):
+def make_problem(cfg, stack, coords, tris, tags, material_tags, k_sample, device_id, precond):
     from heatflow_amd.bc import P1Space, RowDirichletBC
     from heatflow_amd.heating import HeatingCurve
     from heatflow_amd.solver import HeatProblem
@@ -66,7 +66,7 @@ def make_problem(cfg, stack, coords, tris, tags, material_tags, k_sample, device
     if k_sample is not None:
         tag_to_k[material_tags["p_sample"]] = float(k_sample)
     dt = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
-    return HeatProblem(coords, tris, tags, tag_to_k, tag_to_rc, dt, bcs, ic, device_id=device_id)
+    return HeatProblem(coords, tris, tags, tag_to_k, tag_to_rc, dt, bcs, ic, device_id=device_id, precond=precond)
 
 
 def cpu_baseline(cfg, mesh, n_sample_steps, first_step):
@@ -105,6 +105,10 @@ def main():
     ap.add_argument("--scale", type=float, default=MESH_SCALE, help="factor on every mats.*.mesh (0.43 -> ~1.04M DOF)")
     ap.add_argument("--cpu-steps", type=int, default=20, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=4, help="extra steps with in-situ SpMV event timing")
+    ap.add_argument("--precond", choices=["amg", "jacobi"], default="amg",
+                    help="PCG preconditioner of the timed run: smoothed-aggregation V-cycle (default) or plain Jacobi")
+    ap.add_argument("--jacobi-steps", type=int, default=10,
+                    help="with --precond amg: also time this many Jacobi-PCG steps for the record (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +152,8 @@ def main():
         del tc, tt, tg
 
     k_sample = None if world == 1 else 3.8 + 0.02 * rank
-    prob = make_problem(cfg, stack, coords, tris, tags, mtags, k_sample, local_rank)
+    precond = 1 if args.precond == "amg" else 0
+    prob = make_problem(cfg, stack, coords, tris, tags, mtags, k_sample, local_rank, precond)
     be = prob.backend
     n, nnz = be.n, be.nnz
     for bc in prob.bcs:
@@ -187,6 +192,23 @@ def main():
         spmv_us = k_us["spmv"]
     achieved = spmv_bytes / (spmv_us * 1e-6) / 1e9
 
+    # ---- for the record: the plain Jacobi-PCG loop (north-star solver) on the same steps
+    jacobi = None
+    if precond == 1 and args.jacobi_steps > 0 and world == 1:
+        amg_info = be.amg_info()
+        be.set_precond(0, False)
+        be.assemble(prob.dt, prob.assembly_mode)
+        prob.set_state(float(cfg["heating"]["ic_temp"]))
+        if args.warmup > 0:
+            prob.run(args.warmup, time_varying=heated, first_step=0)
+        tj = time.perf_counter()
+        _, _, itj = prob.run(args.jacobi_steps, time_varying=heated, first_step=args.warmup)
+        tj = time.perf_counter() - tj
+        jacobi = {"steps": args.jacobi_steps, "ms_per_step": 1e3 * tj / args.jacobi_steps,
+                  "pcg_iters_per_step_mean": float(np.mean(itj)), "value": n * args.jacobi_steps / tj}
+    elif precond == 1:
+        amg_info = be.amg_info()
+
     if rank == 0:
         out = {
             "metric": "DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond", "value": world * n * args.steps / elapsed,
@@ -196,6 +218,8 @@ def main():
             "config": {"workload": f"cfgs/geballe_with_diamond.yaml, every mats.*.mesh x {args.scale} (BASELINE C3, ~1M DOF), "
                                    f"steps {args.warmup}..{args.warmup + args.steps - 1} of 100, dt=7.5e-8 s",
                        "n_dof": n, "n_elem": be.n_e, "nnz": nnz, "n_dirichlet": be.n_bc,
+                       "solver": ("PCG + smoothed-aggregation multigrid V(1,1), damped-Jacobi smoothing" if precond
+                                  else "Jacobi-PCG"),
                        "pcg_rtol": prob.rtol, "pcg_iters_per_step_mean": float(np.mean(iters)),
                        "pcg_iters_per_step_max": int(np.max(iters)),
                        "points": "1 sweep point per GPU (kappa_sample = 3.8 + 0.02*rank)" if world > 1 else "1 run",
@@ -205,6 +229,10 @@ def main():
                          "bytes_per_launch": spmv_bytes, "us_per_launch": spmv_us,
                          "us_back_to_back": k_us},
         }
+        if precond == 1:
+            out["config"]["amg"] = amg_info
+        if jacobi is not None:
+            out["config"]["jacobi_pcg"] = jacobi
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, mesh, args.cpu_steps, args.warmup)
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

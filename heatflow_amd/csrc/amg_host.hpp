@@ -1,0 +1,271 @@
+// Host-side set-up of a smoothed-aggregation multigrid hierarchy for the SPD operator
+// A_hat = M + dt K (Dirichlet rows = identity).  Plain C++ (no HIP): strength graph,
+// greedy aggregation, Jacobi-smoothed prolongator P = (I - w D^-1 A) T, Galerkin
+// A_c = P^T A P, dense inverse of the coarsest operator.  The V-cycle itself runs on the GPU
+// (heatflow_hip.hip) with the same CSR SpMV kernels as the PCG loop.
+//
+// This has no counterpart in the reference (it factors with MUMPS, run_with_diamond.py:389-394);
+// it is the preconditioner that lets PCG reach the reference's answer in ~15 instead of ~800
+// iterations on the 1M-DOF mesh.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace amg {
+
+struct Csr {
+  int nrow = 0, ncol = 0;
+  std::vector<int> ptr, idx;
+  std::vector<double> val;
+  int64_t nnz() const { return static_cast<int64_t>(idx.size()); }
+};
+
+inline Csr transpose(const Csr& A) {
+  Csr T;
+  T.nrow = A.ncol;
+  T.ncol = A.nrow;
+  T.ptr.assign(static_cast<size_t>(A.ncol) + 1, 0);
+  for (int c : A.idx) T.ptr[c + 1]++;
+  for (int i = 0; i < A.ncol; ++i) T.ptr[i + 1] += T.ptr[i];
+  T.idx.resize(A.idx.size());
+  T.val.resize(A.val.size());
+  std::vector<int> cur(T.ptr.begin(), T.ptr.end() - 1);
+  for (int i = 0; i < A.nrow; ++i)
+    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+      const int q = cur[A.idx[k]]++;
+      T.idx[q] = i;  // rows visited in increasing order -> sorted columns
+      T.val[q] = A.val[k];
+    }
+  return T;
+}
+
+// C = A * B (Gustavson, dense accumulator), columns of every row sorted.
+inline Csr spgemm(const Csr& A, const Csr& B) {
+  Csr C;
+  C.nrow = A.nrow;
+  C.ncol = B.ncol;
+  C.ptr.assign(static_cast<size_t>(A.nrow) + 1, 0);
+  std::vector<double> acc(B.ncol, 0.0);
+  std::vector<int> mark(B.ncol, -1), cols;
+  C.idx.reserve(A.idx.size() * 2);
+  C.val.reserve(A.idx.size() * 2);
+  for (int i = 0; i < A.nrow; ++i) {
+    cols.clear();
+    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+      const int a = A.idx[k];
+      const double av = A.val[k];
+      for (int q = B.ptr[a]; q < B.ptr[a + 1]; ++q) {
+        const int j = B.idx[q];
+        if (mark[j] != i) { mark[j] = i; acc[j] = 0.0; cols.push_back(j); }
+        acc[j] += av * B.val[q];
+      }
+    }
+    std::sort(cols.begin(), cols.end());
+    for (int j : cols) { C.idx.push_back(j); C.val.push_back(acc[j]); }
+    C.ptr[i + 1] = static_cast<int>(C.idx.size());
+  }
+  return C;
+}
+
+inline std::vector<double> diagonal(const Csr& A) {
+  std::vector<double> d(A.nrow, 0.0);
+  for (int i = 0; i < A.nrow; ++i)
+    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k)
+      if (A.idx[k] == i) d[i] = A.val[k];
+  return d;
+}
+
+// Greedy aggregation on the strength graph |a_ij| >= theta sqrt(a_ii a_jj) (Vanek et al.):
+// pass 1 roots whose whole strong neighbourhood is free, pass 2 attaches leftovers to the
+// aggregate of their strongest aggregated neighbour (pass-1 state), pass 3 groups the rest.
+// Nodes without strong connections (Dirichlet rows, diagonally dominant rows) get agg = -1:
+// they take no coarse correction, the Jacobi smoother treats them.
+inline int aggregate(const Csr& A, const std::vector<double>& d, double theta, std::vector<int>& agg) {
+  const int n = A.nrow;
+  std::vector<int> sptr(static_cast<size_t>(n) + 1, 0), sidx;
+  std::vector<double> sval;
+  sidx.reserve(A.idx.size());
+  sval.reserve(A.idx.size());
+  const double t2 = theta * theta;
+  for (int i = 0; i < n; ++i) {
+    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+      const int j = A.idx[k];
+      const double v = A.val[k];
+      if (j != i && v != 0.0 && v * v >= t2 * d[i] * d[j]) { sidx.push_back(j); sval.push_back(std::fabs(v)); }
+    }
+    sptr[i + 1] = static_cast<int>(sidx.size());
+  }
+  agg.assign(n, -1);
+  int na = 0;
+  for (int i = 0; i < n; ++i) {                       // pass 1
+    if (agg[i] != -1 || sptr[i] == sptr[i + 1]) continue;
+    bool free_nb = true;
+    for (int k = sptr[i]; k < sptr[i + 1] && free_nb; ++k) free_nb = agg[sidx[k]] == -1;
+    if (!free_nb) continue;
+    agg[i] = na;
+    for (int k = sptr[i]; k < sptr[i + 1]; ++k) agg[sidx[k]] = na;
+    ++na;
+  }
+  std::vector<int> agg1(agg);
+  for (int i = 0; i < n; ++i) {                       // pass 2
+    if (agg1[i] != -1 || sptr[i] == sptr[i + 1]) continue;
+    double best = -1.0;
+    int who = -1;
+    for (int k = sptr[i]; k < sptr[i + 1]; ++k)
+      if (agg1[sidx[k]] != -1 && sval[k] > best) { best = sval[k]; who = agg1[sidx[k]]; }
+    if (who >= 0) agg[i] = who;
+  }
+  for (int i = 0; i < n; ++i) {                       // pass 3
+    if (agg[i] != -1 || sptr[i] == sptr[i + 1]) continue;
+    agg[i] = na;
+    for (int k = sptr[i]; k < sptr[i + 1]; ++k)
+      if (agg[sidx[k]] == -1) agg[sidx[k]] = na;
+    ++na;
+  }
+  return na;
+}
+
+// P = (I - w D^-1 A) T with T the piecewise-constant aggregate indicator.
+inline Csr smoothed_prolongator(const Csr& A, const std::vector<double>& d, const std::vector<int>& agg, int na,
+                                double w) {
+  Csr P;
+  P.nrow = A.nrow;
+  P.ncol = na;
+  P.ptr.assign(static_cast<size_t>(A.nrow) + 1, 0);
+  std::vector<double> acc(na, 0.0);
+  std::vector<int> mark(na, -1), cols;
+  for (int i = 0; i < A.nrow; ++i) {
+    cols.clear();
+    if (agg[i] >= 0) { mark[agg[i]] = i; acc[agg[i]] = 1.0; cols.push_back(agg[i]); }
+    // rows without an aggregate stay zero: (I - w D^-1 A) T has the row -w/d_i sum_j a_ij T_j, which is
+    // dropped on purpose so that isolated / Dirichlet rows receive no coarse correction
+    if (agg[i] >= 0) {
+      const double s = -w / d[i];
+      for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+        const int c = agg[A.idx[k]];
+        if (c < 0) continue;
+        if (mark[c] != i) { mark[c] = i; acc[c] = 0.0; cols.push_back(c); }
+        acc[c] += s * A.val[k];
+      }
+    }
+    std::sort(cols.begin(), cols.end());
+    for (int c : cols) { P.idx.push_back(c); P.val.push_back(acc[c]); }
+    P.ptr[i + 1] = static_cast<int>(P.idx.size());
+  }
+  return P;
+}
+
+inline double gershgorin_rho(const Csr& A, const std::vector<double>& d) {  // bound on lambda_max(D^-1 A)
+  double rho = 0.0;
+  for (int i = 0; i < A.nrow; ++i) {
+    double s = 0.0;
+    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) s += std::fabs(A.val[k]);
+    rho = std::max(rho, s / d[i]);
+  }
+  return rho;
+}
+
+// Dense inverse by Gauss-Jordan with partial pivoting (coarsest level, n <= ~1000).
+inline bool dense_inverse(const Csr& A, std::vector<double>& inv) {
+  const int n = A.nrow;
+  std::vector<double> a(static_cast<size_t>(n) * n, 0.0);
+  inv.assign(static_cast<size_t>(n) * n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) a[static_cast<size_t>(i) * n + A.idx[k]] = A.val[k];
+    inv[static_cast<size_t>(i) * n + i] = 1.0;
+  }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (std::fabs(a[static_cast<size_t>(r) * n + c]) > std::fabs(a[static_cast<size_t>(piv) * n + c])) piv = r;
+    if (a[static_cast<size_t>(piv) * n + c] == 0.0) return false;
+    if (piv != c)
+      for (int j = 0; j < n; ++j) {
+        std::swap(a[static_cast<size_t>(piv) * n + j], a[static_cast<size_t>(c) * n + j]);
+        std::swap(inv[static_cast<size_t>(piv) * n + j], inv[static_cast<size_t>(c) * n + j]);
+      }
+    const double s = 1.0 / a[static_cast<size_t>(c) * n + c];
+    for (int j = 0; j < n; ++j) { a[static_cast<size_t>(c) * n + j] *= s; inv[static_cast<size_t>(c) * n + j] *= s; }
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = a[static_cast<size_t>(r) * n + c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < n; ++j) {
+        a[static_cast<size_t>(r) * n + j] -= f * a[static_cast<size_t>(c) * n + j];
+        inv[static_cast<size_t>(r) * n + j] -= f * inv[static_cast<size_t>(c) * n + j];
+      }
+    }
+  }
+  return true;
+}
+
+struct Level {
+  Csr A;                    // operator of this level (level 0: not stored here, the caller owns it)
+  Csr P, R;                 // to / from the next coarser level (empty on the coarsest)
+  std::vector<double> dinv;
+  double omega = 0.0;       // Jacobi damping 4 / (3 rho)
+};
+
+struct Hierarchy {
+  std::vector<Level> levels;          // levels[0].A is left empty (the fine operator lives on the device)
+  std::vector<double> coarse_inv;     // dense inverse of the coarsest A
+  int coarse_n = 0;
+  double op_complexity = 0.0;
+};
+
+struct Params {
+  double theta = 0.08;      // strength threshold on level 0, halved per level
+  int coarse_size = 400;    // stop when a level has at most this many rows
+  int max_levels = 12;
+};
+
+// Build from the fine operator A0 (moved in; released after the first Galerkin product).
+inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
+  H.levels.clear();
+  Csr A = std::move(A0);
+  const double nnz0 = static_cast<double>(A.nnz());
+  double nnz_sum = nnz0;
+  for (int lev = 0;; ++lev) {
+    Level L;
+    std::vector<double> d = diagonal(A);
+    for (double v : d)
+      if (!(v > 0.0)) return false;
+    L.dinv.resize(d.size());
+    for (size_t i = 0; i < d.size(); ++i) L.dinv[i] = 1.0 / d[i];
+    const double rho = gershgorin_rho(A, d);
+    L.omega = 4.0 / (3.0 * rho);
+    const bool last = A.nrow <= prm.coarse_size || lev + 1 >= prm.max_levels;
+    if (!last) {
+      std::vector<int> agg;
+      const int na = aggregate(A, d, prm.theta * std::pow(0.5, lev), agg);
+      if (na == 0 || na > 0.8 * A.nrow) {            // coarsening stalled: finish here
+        L.A = std::move(A);
+        H.levels.push_back(std::move(L));
+        break;
+      }
+      L.P = smoothed_prolongator(A, d, agg, na, L.omega);
+      L.R = transpose(L.P);
+      Csr AP = spgemm(A, L.P);
+      Csr Ac = spgemm(L.R, AP);
+      if (lev > 0) L.A = std::move(A);               // level 0's operator stays with the caller
+      H.levels.push_back(std::move(L));
+      A = std::move(Ac);
+      nnz_sum += static_cast<double>(A.nnz());
+    } else {
+      L.A = std::move(A);
+      H.levels.push_back(std::move(L));
+      break;
+    }
+  }
+  const Csr& Ac = H.levels.back().A;
+  H.coarse_n = Ac.nrow;
+  H.op_complexity = nnz_sum / nnz0;
+  if (H.levels.size() == 1) { H.coarse_n = 0; return true; }  // no coarsening possible: plain Jacobi
+  if (Ac.nrow > 4096) { H.coarse_inv.clear(); return true; }   // too big for a dense inverse: Jacobi sweeps
+  return dense_inverse(Ac, H.coarse_inv);
+}
+
+}  // namespace amg

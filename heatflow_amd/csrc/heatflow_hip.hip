@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -21,6 +22,7 @@
 #include <string>
 #include <vector>
 
+#include "amg_host.hpp"
 #include "heatflow_hip.h"
 
 namespace {
@@ -87,6 +89,17 @@ struct hf_ctx {
   double* d_samp = nullptr;
   int samp_cap = 0;
   int pred_iters = 0;
+  // multigrid preconditioner (hf_set_precond): device hierarchy
+  int precond = 0;             // 0 Jacobi, 1 smoothed-aggregation AMG V(1,1)
+  int amg_reuse = 0;           // 1: keep the coarse levels across hf_assemble calls (kappa sweeps)
+  bool amg_ready = false;
+  struct DevCsr { int nrow = 0, ncol = 0, lanes = 8; int64_t nnz = 0; int32_t *ptr = nullptr, *idx = nullptr; double* val = nullptr; };
+  struct DevLevel { DevCsr A, P, R; double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr; double omega = 0; int n = 0; };
+  std::vector<DevLevel> amg;
+  double* d_coarse_inv = nullptr;
+  int coarse_n = 0;
+  double amg_opc = 0.0, amg_setup_s = 0.0;
+  double *d_z = nullptr, *d_z2 = nullptr;
   // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
@@ -363,6 +376,9 @@ __global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* 
 //   MODE 0: y = A x
 //   MODE 1: y = A x and partial sums of x.y             (PCG: Ap, p.Ap)
 //   MODE 2: r = b - A x; p = D^-1 r; partials r.p, p.p, (D^-1 b)^2   (PCG start)
+//   MODE 3: y = b - A x                                              (multigrid residual)
+//   MODE 4: y = x + w D^-1 (b - A x), partials b.y                   (damped-Jacobi sweep, fused r.z)
+//   MODE 5: y = b - A x; p = w D^-1 y; partials (D^-1 y)^2, (D^-1 b)^2   (AMG-PCG start)
 // ------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(TPB) void k_spmv(int n, int nchunks, const int32_t* __restrict__ rowptr,
@@ -371,10 +387,10 @@ __global__ __launch_bounds__(TPB) void k_spmv(int n, int nchunks, const int32_t*
                                               double* __restrict__ y, const Scal* __restrict__ scal,
                                               double* __restrict__ part0, const double* __restrict__ bvec,
                                               const double* __restrict__ dinv, double* __restrict__ pvec,
-                                              double* __restrict__ part1, double* __restrict__ part2) {
+                                              double* __restrict__ part1, double* __restrict__ part2, double w) {
   extern __shared__ double sprod[];
   __shared__ double s4[4];
-  if (MODE == 1 && scal->done) return;
+  if ((MODE == 1 || MODE == 3 || MODE == 4) && scal->done) return;
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const int r0 = chunk * RB;
@@ -393,7 +409,7 @@ __global__ __launch_bounds__(TPB) void k_spmv(int n, int nchunks, const int32_t*
       } else if (MODE == 1) {
         y[row] = s;
         acc0 += x[row] * s;
-      } else {
+      } else if (MODE == 2) {
         const double bi = bvec[row], di = dinv[row];
         const double ri = bi - s;
         const double zi = di * ri;
@@ -402,15 +418,29 @@ __global__ __launch_bounds__(TPB) void k_spmv(int n, int nchunks, const int32_t*
         acc0 += ri * zi;
         acc1 += zi * zi;
         acc2 += (di * bi) * (di * bi);
+      } else if (MODE == 3) {
+        y[row] = bvec[row] - s;
+      } else if (MODE == 4) {
+        const double bi = bvec[row];
+        const double yi = x[row] + w * dinv[row] * (bi - s);
+        y[row] = yi;
+        acc0 += bi * yi;
+      } else {
+        const double bi = bvec[row], di = dinv[row];
+        const double ri = bi - s;
+        y[row] = ri;
+        pvec[row] = w * di * ri;
+        acc1 += (di * ri) * (di * ri);
+        acc2 += (di * bi) * (di * bi);
       }
     }
     __syncthreads();
   }
-  if (MODE >= 1) {
+  if (MODE == 1 || MODE == 2 || MODE == 4) {
     const double t0 = block_sum(acc0, s4);
     if (threadIdx.x == 0) part0[blockIdx.x] = t0;
   }
-  if (MODE == 2) {
+  if (MODE == 2 || MODE == 5) {
     const double t1 = block_sum(acc1, s4);
     const double t2 = block_sum(acc2, s4);
     if (threadIdx.x == 0) { part1[blockIdx.x] = t1; part2[blockIdx.x] = t2; }
@@ -489,6 +519,120 @@ __global__ __launch_bounds__(TPB) void k_pcg_dir(int n, int nchunks, int P, int 
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const int i = chunk * RB + threadIdx.x;
     if (i < n) p[i] = dinv[i] * r[i] + beta * p[i];
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Generic CSR SpMV for the multigrid transfer operators and coarse levels: LANES lanes of a
+// wavefront share one row (4..64 by the average row length), fixed-order shuffle reduction.
+//   VMODE 0: y = A x      1: y += A x      2: y = b - A x      3: y = x + w D^-1 (b - A x)
+// ------------------------------------------------------------------------------------------
+template <int LANES, int VMODE>
+__global__ __launch_bounds__(TPB) void k_spmv_vec(int nrow, const int32_t* __restrict__ ptr,
+                                                  const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                  const double* __restrict__ x, double* __restrict__ y,
+                                                  const double* __restrict__ b, const double* __restrict__ dinv,
+                                                  double w, const Scal* __restrict__ scal) {
+  if (scal->done) return;
+  const int lane = threadIdx.x % LANES;
+  const int rows_per_pass = (gridDim.x * TPB) / LANES;
+  for (int row = (blockIdx.x * TPB + threadIdx.x) / LANES; row < nrow; row += rows_per_pass) {
+    double s = 0.0;
+    const int k1 = ptr[row + 1];
+    for (int k = ptr[row] + lane; k < k1; k += LANES) s += val[k] * x[idx[k]];
+#pragma unroll
+    for (int o = LANES / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LANES);
+    if (lane == 0) {
+      if (VMODE == 0) y[row] = s;
+      else if (VMODE == 1) y[row] += s;
+      else if (VMODE == 2) y[row] = b[row] - s;
+      else y[row] = x[row] + w * dinv[row] * (b[row] - s);
+    }
+  }
+}
+
+// x = w D^-1 b  (first damped-Jacobi sweep from a zero guess)
+__global__ __launch_bounds__(TPB) void k_scale(int n, double w, const double* __restrict__ dinv,
+                                               const double* __restrict__ b, double* __restrict__ x,
+                                               const Scal* __restrict__ scal) {
+  if (scal->done) return;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) x[i] = w * dinv[i] * b[i];
+}
+
+// x = Ainv b with the dense inverse of the coarsest operator: one wavefront per row.
+__global__ __launch_bounds__(TPB) void k_dense_mv(int n, const double* __restrict__ Ainv, const double* __restrict__ b,
+                                                  double* __restrict__ x, const Scal* __restrict__ scal) {
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * TPB) >> 6;
+  for (int row = wave; row < n; row += nwaves) {
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) s += Ainv[static_cast<size_t>(row) * n + j] * b[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) x[row] = s;
+  }
+}
+
+// AMG-PCG: x += alpha p; r -= alpha Ap; z0 = w D^-1 r (pre-smoothed start of the V-cycle);
+// partial (D^-1 r)^2 for the convergence test.  r.z comes from the V-cycle's last kernel.
+__global__ __launch_bounds__(TPB) void k_pcg_update_amg(int n, int nchunks, int P, int parity, Scal* __restrict__ scal,
+                                                        const double* __restrict__ part_pAp,
+                                                        const double* __restrict__ part_rz, double* __restrict__ part_zz,
+                                                        double* __restrict__ x, double* __restrict__ r,
+                                                        const double* __restrict__ p, const double* __restrict__ Ap,
+                                                        const double* __restrict__ dinv, double w, double* __restrict__ z0) {
+  __shared__ double s4[4];
+  if (scal->done) return;
+  const double pAp = sum_partials(part_pAp, P, s4);
+  const double rz = sum_partials(part_rz + parity * MAXP, P, s4);
+  if (!(pAp > 0.0)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal->done = 2;
+    return;
+  }
+  const double alpha = rz / pAp;
+  double a_zz = 0.0;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int i = chunk * RB + threadIdx.x;
+    if (i < n) {
+      const double ri = r[i] - alpha * Ap[i];
+      const double zi = dinv[i] * ri;
+      x[i] += alpha * p[i];
+      r[i] = ri;
+      z0[i] = w * zi;
+      a_zz += zi * zi;
+    }
+  }
+  const double t1 = block_sum(a_zz, s4);
+  if (threadIdx.x == 0) part_zz[blockIdx.x] = t1;
+}
+
+// AMG-PCG: convergence test on (D^-1 r)^2, beta = rz_new/rz_old, p = z + beta p (first: p = z).
+__global__ __launch_bounds__(TPB) void k_pcg_dir_amg(int n, int nchunks, int P, int parity, int first,
+                                                     Scal* __restrict__ scal, const double* __restrict__ part_rz,
+                                                     const double* __restrict__ part_zz, const double* __restrict__ z,
+                                                     double* __restrict__ p) {
+  __shared__ double s4[4];
+  if (scal->done) return;
+  double beta = 0.0;
+  if (!first) {
+    const double rz_old = sum_partials(part_rz + parity * MAXP, P, s4);
+    const double rz_new = sum_partials(part_rz + (parity ^ 1) * MAXP, P, s4);
+    const double zz = sum_partials(part_zz, P, s4);
+    const bool conv = zz <= scal->tol2;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      scal->zz = zz;
+      scal->iters += 1;
+      if (conv) scal->done = 1;
+    }
+    if (conv) return;
+    beta = rz_new / rz_old;
+  }
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int i = chunk * RB + threadIdx.x;
+    if (i < n) p[i] = first ? z[i] : z[i] + beta * p[i];
   }
 }
 
@@ -609,9 +753,9 @@ int launch_assemble(hf_ctx* ctx) {
 template <int MODE>
 void launch_spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr,
                  const double* bvec = nullptr, double* pvec = nullptr, double* part1 = nullptr,
-                 double* part2 = nullptr) {
+                 double* part2 = nullptr, double w = 0.0) {
   hipLaunchKernelGGL(k_spmv<MODE>, dim3(c->P), dim3(TPB), spmv_smem_bytes(c), c->stream, c->n, c->nchunks,
-                     c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, c->d_dinv, pvec, part1, part2);
+                     c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, c->d_dinv, pvec, part1, part2, w);
 }
 
 constexpr int PROF_PAIRS = 64;
@@ -625,6 +769,160 @@ void launch_pcg_iteration(hf_ctx* c, int parity) {
                      c->d_part_pAp, c->d_part_rz, c->d_part_zz, c->d_u, c->d_r, c->d_p, c->d_Ap, c->d_dinv);
   hipLaunchKernelGGL(k_pcg_dir, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
                      c->d_part_rz, c->d_part_zz, c->d_r, c->d_p, c->d_dinv);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// multigrid: hierarchy upload, V-cycle, AMG-PCG step
+// ------------------------------------------------------------------------------------------
+using DevCsr = hf_ctx::DevCsr;
+using DevLevel = hf_ctx::DevLevel;
+
+void free_dev_csr(DevCsr& m) { dev_free(&m.ptr); dev_free(&m.idx); dev_free(&m.val); m = DevCsr(); }
+
+void free_amg(hf_ctx* ctx) {
+  for (size_t l = 0; l < ctx->amg.size(); ++l) {
+    DevLevel& L = ctx->amg[l];
+    if (l > 0) { free_dev_csr(L.A); dev_free(&L.dinv); dev_free(&L.x); dev_free(&L.b); }
+    free_dev_csr(L.P); free_dev_csr(L.R);
+    dev_free(&L.x2); dev_free(&L.r);
+  }
+  ctx->amg.clear();
+  dev_free(&ctx->d_coarse_inv);
+  ctx->coarse_n = 0;
+  ctx->amg_ready = false;
+}
+
+int lanes_for(const amg::Csr& m) {
+  const double avg = m.nrow ? static_cast<double>(m.nnz()) / m.nrow : 1.0;
+  return avg <= 4.5 ? 4 : avg <= 9.0 ? 8 : avg <= 18.0 ? 16 : avg <= 36.0 ? 32 : 64;
+}
+
+int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d) {
+  d.nrow = h.nrow; d.ncol = h.ncol; d.nnz = h.nnz(); d.lanes = lanes_for(h);
+  HF_TRY(dev_alloc(ctx, &d.ptr, h.ptr.size()));
+  HF_TRY(dev_alloc(ctx, &d.idx, h.idx.size()));
+  HF_TRY(dev_alloc(ctx, &d.val, h.val.size()));
+  HF_HIP(hipMemcpy(d.ptr, h.ptr.data(), sizeof(int32_t) * h.ptr.size(), hipMemcpyHostToDevice));
+  if (!h.idx.empty()) {
+    HF_HIP(hipMemcpy(d.idx, h.idx.data(), sizeof(int32_t) * h.idx.size(), hipMemcpyHostToDevice));
+    HF_HIP(hipMemcpy(d.val, h.val.data(), sizeof(double) * h.val.size(), hipMemcpyHostToDevice));
+  }
+  return HF_OK;
+}
+
+// Build the hierarchy from the assembled, eliminated fine operator (download -> host set-up -> upload).
+int build_amg(hf_ctx* ctx) {
+  const auto t0 = std::chrono::steady_clock::now();
+  free_amg(ctx);
+  amg::Csr A0;
+  A0.nrow = A0.ncol = ctx->n;
+  A0.ptr.assign(ctx->h_rowptr.begin(), ctx->h_rowptr.end());
+  A0.idx.assign(ctx->h_colidx.begin(), ctx->h_colidx.end());
+  A0.val.resize(ctx->nnz);
+  HF_HIP(hipMemcpy(A0.val.data(), ctx->d_A, sizeof(double) * ctx->nnz, hipMemcpyDeviceToHost));
+  amg::Hierarchy H;
+  if (!amg::build(std::move(A0), amg::Params(), H)) return fail(ctx, HF_ERR_STATE, "AMG set-up failed (non-positive diagonal or singular coarse operator)");
+  const size_t nl = H.levels.size();
+  ctx->amg.resize(nl);
+  for (size_t l = 0; l < nl; ++l) {
+    DevLevel& L = ctx->amg[l];
+    const amg::Level& hl = H.levels[l];
+    L.n = static_cast<int>(hl.dinv.size());
+    L.omega = hl.omega;
+    if (l == 0) {
+      L.A.nrow = L.A.ncol = ctx->n; L.A.nnz = ctx->nnz; L.A.ptr = ctx->d_rowptr; L.A.idx = ctx->d_colidx; L.A.val = ctx->d_A;
+      L.dinv = ctx->d_dinv;
+    } else {
+      HF_TRY(upload_csr(ctx, hl.A, L.A));
+      HF_TRY(dev_alloc(ctx, &L.dinv, L.n));
+      HF_HIP(hipMemcpy(L.dinv, hl.dinv.data(), sizeof(double) * L.n, hipMemcpyHostToDevice));
+      HF_TRY(dev_alloc(ctx, &L.x, L.n));
+      HF_TRY(dev_alloc(ctx, &L.b, L.n));
+      HF_TRY(dev_alloc(ctx, &L.x2, L.n));
+      HF_TRY(dev_alloc(ctx, &L.r, L.n));
+    }
+    if (l + 1 < nl) { HF_TRY(upload_csr(ctx, hl.P, L.P)); HF_TRY(upload_csr(ctx, hl.R, L.R)); }
+  }
+  ctx->coarse_n = static_cast<int>(H.coarse_inv.empty() ? 0 : H.coarse_n);
+  if (ctx->coarse_n > 0) {
+    HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv, H.coarse_inv.size()));
+    HF_HIP(hipMemcpy(ctx->d_coarse_inv, H.coarse_inv.data(), sizeof(double) * H.coarse_inv.size(), hipMemcpyHostToDevice));
+  }
+  ctx->amg_opc = H.op_complexity;
+  ctx->amg_ready = true;
+  ctx->amg_setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return HF_OK;
+}
+
+template <int VMODE>
+void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y, const double* b = nullptr,
+                const double* dinv = nullptr, double w = 0.0) {
+  const int lanes = m.lanes;
+  const long long threads = static_cast<long long>(m.nrow) * lanes;
+  const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 2048)));
+#define HF_VEC(L) hipLaunchKernelGGL((k_spmv_vec<L, VMODE>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, m.val, x, y, b, dinv, w, c->d_scal)
+  switch (lanes) {
+    case 4: HF_VEC(4); break;
+    case 8: HF_VEC(8); break;
+    case 16: HF_VEC(16); break;
+    case 32: HF_VEC(32); break;
+    default: HF_VEC(64); break;
+  }
+#undef HF_VEC
+}
+
+// z = B r: one V(1,1) cycle.  On entry d_z holds w0 D^-1 r (written by the update / start kernel);
+// on exit d_z holds the result and part_rz[out_slot] the partials of r.z.
+void vcycle(hf_ctx* c, int out_slot) {
+  const int nl = static_cast<int>(c->amg.size());
+  DevLevel& L0 = c->amg[0];
+  if (nl == 1) {  // no coarse level: one more Jacobi sweep keeps the operator symmetric
+    launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
+    std::swap(c->d_z, c->d_z2);
+    return;
+  }
+  launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r);                 // t = r - A z
+  launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);                                // b1 = R0 t
+  for (int l = 1; l + 1 < nl; ++l) {
+    DevLevel& L = c->amg[l];
+    const int g = std::max(1, std::min((L.n + TPB - 1) / TPB, 1024));
+    hipLaunchKernelGGL(k_scale, dim3(g), dim3(TPB), 0, c->stream, L.n, L.omega, L.dinv, L.b, L.x, c->d_scal);
+    launch_vec<2>(c, L.A, L.x, L.r, L.b);                                       // r_l = b_l - A_l x_l
+    launch_vec<0>(c, L.R, L.r, c->amg[l + 1].b);                                // b_{l+1} = R_l r_l
+  }
+  {
+    DevLevel& Lc = c->amg[nl - 1];
+    if (c->coarse_n > 0) {
+      const int g = std::max(1, std::min((Lc.n * 64 + TPB - 1) / TPB, 1024));
+      hipLaunchKernelGGL(k_dense_mv, dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->d_coarse_inv, Lc.b, Lc.x, c->d_scal);
+    } else {
+      const int g = std::max(1, std::min((Lc.n + TPB - 1) / TPB, 1024));
+      hipLaunchKernelGGL(k_scale, dim3(g), dim3(TPB), 0, c->stream, Lc.n, Lc.omega, Lc.dinv, Lc.b, Lc.x, c->d_scal);
+    }
+  }
+  for (int l = nl - 2; l >= 1; --l) {
+    DevLevel& L = c->amg[l];
+    launch_vec<1>(c, L.P, c->amg[l + 1].x, L.x);                                // x_l += P_l x_{l+1}
+    launch_vec<3>(c, L.A, L.x, L.x2, L.b, L.dinv, L.omega);                     // post-smooth
+    std::swap(L.x, L.x2);
+  }
+  launch_vec<1>(c, L0.P, c->amg[1].x, c->d_z);                                  // z += P0 x_1
+  launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
+  std::swap(c->d_z, c->d_z2);
+}
+
+void launch_amg_iteration(hf_ctx* c, int parity) {
+  const bool timed = c->prof && c->prof_used < PROF_PAIRS;
+  if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_used], c->stream);
+  launch_spmv<1>(c, c->d_A, c->d_p, c->d_Ap, c->d_part_pAp);
+  if (timed) { (void)hipEventRecord(c->prof_ev[2 * c->prof_used + 1], c->stream); c->prof_used++; }
+  hipLaunchKernelGGL(k_pcg_update_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
+                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, c->d_u, c->d_r, c->d_p, c->d_Ap, c->d_dinv,
+                     c->amg[0].omega, c->d_z);
+  vcycle(c, parity ^ 1);
+  hipLaunchKernelGGL(k_pcg_dir_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, 0, c->d_scal,
+                     c->d_part_rz, c->d_part_zz, c->d_z, c->d_p);
 }
 
 int read_scal(hf_ctx* ctx) {
@@ -657,11 +955,24 @@ int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
     hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, ctx->d_g,
                        ctx->d_b, ctx->d_u);
   }
-  // r = b - A u, p = z = D^-1 r
-  launch_spmv<2>(ctx, ctx->d_A, ctx->d_u, ctx->d_r, ctx->d_part_rz, ctx->d_b, ctx->d_p, ctx->d_part_zz,
-                 ctx->d_part_bn);
-  hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
-                     ctx->d_part_bn, ctx->d_scal);
+  const bool use_amg = ctx->precond == 1 && ctx->amg_ready;
+  if (!use_amg) {
+    // r = b - A u, p = z = D^-1 r
+    launch_spmv<2>(ctx, ctx->d_A, ctx->d_u, ctx->d_r, ctx->d_part_rz, ctx->d_b, ctx->d_p, ctx->d_part_zz,
+                   ctx->d_part_bn);
+    hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
+                       ctx->d_part_bn, ctx->d_scal);
+  } else {
+    // r = b - A u, z0 = w D^-1 r; tolerance; z = B r (V-cycle, r.z into slot 0); p = z
+    HF_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(Scal), ctx->stream));   // done = 0 so the start kernels run
+    launch_spmv<5>(ctx, ctx->d_A, ctx->d_u, ctx->d_r, nullptr, ctx->d_b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn,
+                   ctx->amg[0].omega);
+    hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
+                       ctx->d_part_bn, ctx->d_scal);
+    vcycle(ctx, 0);
+    hipLaunchKernelGGL(k_pcg_dir_amg, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, ctx->nchunks, ctx->P, 0, 1,
+                       ctx->d_scal, ctx->d_part_rz, ctx->d_part_zz, ctx->d_z, ctx->d_p);
+  }
   HF_HIP(hipGetLastError());
 
   int launched = 0;
@@ -670,17 +981,20 @@ int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
     if (ctx->h_scal->done == 1) return HF_OK;
   }
   // first burst: what the previous step needed (the counts drift slowly), then check in small bursts
-  int burst = std::max(2, std::min(max_it, ctx->pred_iters > 0 ? ctx->pred_iters : 32));
+  int burst = std::max(2, std::min(max_it, ctx->pred_iters > 0 ? ctx->pred_iters : (use_amg ? 8 : 32)));
   while (true) {
     burst += burst & 1;  // parity pairs
     ctx->prof_base = launched;
-    for (int k = 0; k < burst; ++k) launch_pcg_iteration(ctx, (launched + k) & 1);
+    for (int k = 0; k < burst; ++k) {
+      if (use_amg) launch_amg_iteration(ctx, (launched + k) & 1);
+      else launch_pcg_iteration(ctx, (launched + k) & 1);
+    }
     launched += burst;
     HF_HIP(hipGetLastError());
     HF_TRY(read_scal(ctx));
     if (ctx->h_scal->done) break;
     if (launched >= max_it) break;
-    burst = std::min(std::max(8, launched / 8), max_it - launched);
+    burst = std::min(std::max(use_amg ? 2 : 8, launched / 8), max_it - launched);
     burst = std::max(burst, 2);
   }
   ctx->pred_iters = ctx->h_scal->iters;
@@ -788,6 +1102,7 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_bc_dofs); dev_free(&ctx->d_g); dev_free(&ctx->d_lift_rows); dev_free(&ctx->d_lift_ptr);
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_u); dev_free(&ctx->d_b); dev_free(&ctx->d_r); dev_free(&ctx->d_p); dev_free(&ctx->d_Ap);
+  free_amg(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
   dev_free(&ctx->d_tmp); dev_free(&ctx->d_part_pAp); dev_free(&ctx->d_part_rz); dev_free(&ctx->d_part_zz);
   dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp);
   for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -848,6 +1163,9 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_TRY(dev_alloc(ctx, &ctx->d_p, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_Ap, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_tmp, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_z, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_z2, n));
+  free_amg(ctx);
   HF_HIP(hipMemcpy(ctx->d_zr, zr, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
   HF_HIP(hipMemcpy(ctx->d_elem, elem.data(), sizeof(int4) * ne, hipMemcpyHostToDevice));
   HF_HIP(hipMemcpy(ctx->d_rowptr, P.rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
@@ -902,6 +1220,7 @@ int hf_set_dirichlet(hf_ctx* ctx, int32_t n_bc, const int32_t* dofs) {
   HF_TRY(dev_alloc(ctx, &ctx->d_g, n_bc));
   if (n_bc > 0) HF_HIP(hipMemcpy(ctx->d_bc_dofs, dofs, sizeof(int32_t) * n_bc, hipMemcpyHostToDevice));
   HF_TRY(build_lift(ctx));
+  free_amg(ctx);
   ctx->assembled = false;  // A_hat depends on the BC set
   return HF_OK;
 }
@@ -931,8 +1250,35 @@ int hf_assemble(hf_ctx* ctx, double dt, int32_t mode) {
   float ms = 0.f;
   HF_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->last_ms = ms;
+  if (ctx->precond == 1 && !(ctx->amg_ready && ctx->amg_reuse)) HF_TRY(build_amg(ctx));
+  if (ctx->precond == 1 && ctx->amg_ready) {  // level 0 aliases the fine operator: refresh its pointers
+    ctx->amg[0].A.val = ctx->d_A;
+    ctx->amg[0].dinv = ctx->d_dinv;
+  }
   ctx->assembled = true;
   ctx->pred_iters = 0;
+  return HF_OK;
+}
+
+int hf_set_precond(hf_ctx* ctx, int32_t kind, int32_t reuse) {
+  if (!ctx) return HF_ERR_ARG;
+  if (kind < 0 || kind > 1) return fail(ctx, HF_ERR_ARG, "hf_set_precond: unknown preconditioner %d", kind);
+  if (kind != ctx->precond) { ctx->assembled = false; ctx->pred_iters = 0; }
+  if (kind == 0) { (void)hipSetDevice(ctx->dev); free_amg(ctx); }
+  ctx->precond = kind;
+  ctx->amg_reuse = reuse ? 1 : 0;
+  return HF_OK;
+}
+
+int hf_get_amg_info(hf_ctx* ctx, int32_t* n_levels, int32_t* level_rows, int32_t max_levels, double* op_complexity,
+                    double* setup_seconds) {
+  if (!ctx) return HF_ERR_ARG;
+  const int nl = ctx->amg_ready ? static_cast<int>(ctx->amg.size()) : 0;
+  if (n_levels) *n_levels = nl;
+  if (level_rows)
+    for (int l = 0; l < nl && l < max_levels; ++l) level_rows[l] = ctx->amg[l].n;
+  if (op_complexity) *op_complexity = ctx->amg_ready ? ctx->amg_opc : 0.0;
+  if (setup_seconds) *setup_seconds = ctx->amg_ready ? ctx->amg_setup_s : 0.0;
   return HF_OK;
 }
 

@@ -16,11 +16,12 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libheatflow_hip.so")
 
 HF_OK, HF_ERR_ARG, HF_ERR_STATE, HF_ERR_HIP, HF_ERR_NOCONV, HF_ERR_ALLOC = 0, -1, -2, -3, -4, -5
 ASM_LDS_ATOMIC, ASM_LDS_COLORED, ASM_GLOBAL_ATOMIC = 0, 1, 2
+PC_JACOBI, PC_AMG = 0, 1
 K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS = range(6)
 
 EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_materials",
-    "hf_set_dirichlet", "hf_assemble", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
+    "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_get_amg_info", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
     "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
 
@@ -82,6 +83,8 @@ def load_library():
         "hf_set_materials": [vp, i32, pi, pd, pd],
         "hf_set_dirichlet": [vp, i32, pi],
         "hf_assemble": [vp, dbl, i32],
+        "hf_set_precond": [vp, i32, i32],
+        "hf_get_amg_info": [vp, pi, pi, i32, pd, pd],
         "hf_set_state": [vp, pd],
         "hf_get_state": [vp, pd],
         "hf_sample": [vp, i32, pi, pd],
@@ -186,6 +189,16 @@ class HeatflowHIP:
         d = _i32(dofs)
         self._check(self._lib.hf_set_dirichlet(self._ctx, len(d), _pi(d) if len(d) else None))
         self._refresh_sizes()
+
+    def set_precond(self, kind=PC_JACOBI, reuse=False):
+        """PC_JACOBI (0) or PC_AMG (1); call before assemble()."""
+        self._check(self._lib.hf_set_precond(self._ctx, int(kind), 1 if reuse else 0))
+
+    def amg_info(self):
+        nl, opc, secs = C.c_int32(), C.c_double(), C.c_double()
+        rows = np.zeros(16, dtype=np.int32)
+        self._check(self._lib.hf_get_amg_info(self._ctx, C.byref(nl), _pi(rows), 16, C.byref(opc), C.byref(secs)))
+        return {"levels": nl.value, "rows": rows[:nl.value].tolist(), "op_complexity": opc.value, "setup_s": secs.value}
 
     def assemble(self, dt, mode=ASM_LDS_ATOMIC):
         self._check(self._lib.hf_assemble(self._ctx, float(dt), int(mode)))

@@ -17,7 +17,7 @@ import numpy as np
 from scipy.spatial import cKDTree
 
 from .bc import gather_bc_values, merge_bcs
-from .hip_backend import ASM_LDS_ATOMIC, HeatflowHIP
+from .hip_backend import ASM_LDS_ATOMIC, PC_AMG, PC_JACOBI, HeatflowHIP
 
 # Default PCG tolerance: at rtol = 1e-10 the temperature field agrees with a sparse
 # direct solve of the same system to ~3e-6 K (measured on the stock and the 1M-DOF
@@ -37,16 +37,20 @@ class HeatProblem:
     bcs : list of RowDirichletBC in application order (later wins on shared DOFs)
     u0 : scalar or (n,) initial temperature
     backend : an object with the HeatflowHIP interface; default = a new HeatflowHIP
+    precond : PC_JACOBI (Jacobi-PCG, the north-star solver) or PC_AMG (PCG preconditioned by a
+              smoothed-aggregation V-cycle: same stopping rule and answer, ~50x fewer iterations)
     """
 
     def __init__(self, coords, tris, tags, tag_to_k, tag_to_rho_cv, dt, bcs, u0, *, backend=None, device_id=0,
-                 assembly_mode=ASM_LDS_ATOMIC, rtol=DEFAULT_RTOL, atol=0.0, max_it=DEFAULT_MAX_IT):
+                 assembly_mode=ASM_LDS_ATOMIC, rtol=DEFAULT_RTOL, atol=0.0, max_it=DEFAULT_MAX_IT,
+                 precond=PC_JACOBI, amg_reuse=False):
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.n = self.coords.shape[0]
         self.dt = float(dt)
         self.bcs = list(bcs)
         self.rtol, self.atol, self.max_it = float(rtol), float(atol), int(max_it)
         self.assembly_mode = assembly_mode
+        self.precond = precond
         self.backend = backend if backend is not None else HeatflowHIP(device_id)
         self._own_backend = backend is None
 
@@ -59,6 +63,7 @@ class HeatProblem:
             self.bc_dofs = np.zeros(0, dtype=np.int32)
             self._owner = self._pos = np.zeros(0, dtype=np.int64)
         self.backend.set_dirichlet(self.bc_dofs)
+        self.backend.set_precond(precond, amg_reuse)
         self.backend.assemble(self.dt, self.assembly_mode)
         u = np.full(self.n, float(u0)) if np.isscalar(u0) else np.asarray(u0, dtype=np.float64)
         self.backend.set_state(u)

@@ -92,6 +92,18 @@ int hf_set_dirichlet(hf_ctx* ctx, int32_t n_bc, const int32_t* dofs);
  * zeroed with unit diagonal (the lifting columns are kept aside) and D^-1 is formed. */
 int hf_assemble(hf_ctx* ctx, double dt, int32_t mode);
 
+/* Preconditioner of the PCG solve: kind 0 = Jacobi (D^-1, the north-star path), kind 1 =
+ * smoothed-aggregation multigrid V(1,1) with damped-Jacobi smoothing, built on the host from the
+ * assembled operator at hf_assemble time and applied on the GPU with CSR SpMV kernels.  With
+ * reuse != 0 the coarse levels are kept across later hf_assemble calls (kappa sweeps on one mesh:
+ * the fine level always uses the current matrix, the frozen coarse levels remain a valid SPD
+ * preconditioner).  Call before hf_assemble.  The stopping criterion of hf_step is the same for both. */
+int hf_set_precond(hf_ctx* ctx, int32_t kind, int32_t reuse);
+/* Hierarchy of the last AMG set-up: level count, rows per level (up to max_levels entries),
+ * operator complexity sum(nnz_l)/nnz_0 and host set-up time.  Any pointer may be NULL. */
+int hf_get_amg_info(hf_ctx* ctx, int32_t* n_levels, int32_t* level_rows, int32_t max_levels, double* op_complexity,
+                    double* setup_seconds);
+
 int hf_set_state(hf_ctx* ctx, const double* u);
 int hf_get_state(hf_ctx* ctx, double* u);
 int hf_sample(hf_ctx* ctx, int32_t n_s, const int32_t* nodes, double* out);

@@ -10,14 +10,16 @@ from heatflow_amd import hip_backend as hb
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.43
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+precond = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 t0 = time.time()
 cfg, stack, mesh = build_case("geballe_with_diamond", scale)
 print("mesh", mesh.stats, "%.1fs" % (time.time() - t0), flush=True)
 t0 = time.time()
-prob = make_problem(cfg, stack, mesh, assembly_mode=mode)
+prob = make_problem(cfg, stack, mesh, assembly_mode=mode, precond=precond)
 be = prob.backend
 print("setup %.2fs  n=%d ne=%d nnz=%d nbc=%d  assemble(+bc) gpu ms=%.3f" % (time.time() - t0, be.n, be.n_e, be.nnz, be.n_bc, be.last_gpu_ms()), flush=True)
 n, nnz, ne = be.n, be.nnz, be.n_e
+if precond: print("amg", be.amg_info(), flush=True)
 times, samples, iters = prob.run(nsteps, watcher_nodes=None, time_varying=[prob.bcs[3]])
 ms = be.last_gpu_ms()
 print("run %d steps: %.2f ms total, %.3f ms/step, iters %s" % (nsteps, ms, ms / nsteps, list(iters)), flush=True)

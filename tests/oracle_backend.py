@@ -32,6 +32,9 @@ class OracleBackend:
         self.tag_to_k = {int(t): float(k) for t, k in zip(tags, kappa)}
         self.tag_to_rc = {int(t): float(c) for t, c in zip(tags, rho_c)}
 
+    def set_precond(self, kind=0, reuse=False):
+        self.precond = kind
+
     def set_dirichlet(self, dofs):
         self.bc_dofs = np.asarray(dofs, dtype=np.int64)
         self.n_bc = len(self.bc_dofs)
