@@ -20,6 +20,7 @@ refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
 """
 import os
 
+os.environ.setdefault("NCCL_DEBUG", "WARN")   # keep RCCL banners out of stdout: one JSON line only
 for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
     os.environ.setdefault(_v, "1")      # the reference pins its workers to 1 thread (parameter_sweep.py:46-53)
 
@@ -115,7 +116,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("HEATFLOW_BENCH_FORCE_DIST") == "1":   # the latter: rehearse the RCCL path on 1 GPU
         import torch                      # torch first: its bundled HIP runtime must be the one both sides use
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -131,7 +132,7 @@ def main():
     if rank == 0:
         cfg, stack, mesh = build_problem_inputs(args.scale)
         coords, tris, tags, mtags = mesh.coords, mesh.tris, mesh.tags, mesh.material_tags
-    if world > 1:
+    if dist is not None:
         import torch
         from heatflow_amd.geometry import build_stack, scale_mesh_sizes
         if rank != 0:
@@ -191,6 +192,16 @@ def main():
     if spmv_us is None:
         spmv_us = k_us["spmv"]
     achieved = spmv_bytes / (spmv_us * 1e-6) / 1e9
+    # HBM traffic of that kernel from the PMC passes kept under profiles/ (rocprofv3 cannot wrap itself):
+    # only quoted when it was collected on exactly this matrix
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
+            pmc = json.load(f)
+        if pmc["n"] == n and pmc["nnz"] == nnz:
+            traffic = pmc["kernels"]["k_spmv<1>"]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     # ---- for the record: the plain Jacobi-PCG loop (north-star solver) on the same steps
     jacobi = None
@@ -225,7 +236,7 @@ def main():
                        "points": "1 sweep point per GPU (kappa_sample = 3.8 + 0.02*rank)" if world > 1 else "1 run",
                        "gpu_ms_per_step_events": gpu_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_spmv<1> (PCG CSR SpMV)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<1> (PCG CSR SpMV)",
                          "bytes_per_launch": spmv_bytes, "us_per_launch": spmv_us,
                          "us_back_to_back": k_us},
         }
