@@ -218,7 +218,7 @@ struct Hierarchy {
 
 struct Params {
   double theta = 0.08;      // strength threshold on level 0, halved per level
-  int coarse_size = 400;    // stop when a level has at most this many rows
+  int coarse_size = 2500;   // stop when a level has at most this many rows (dense inverse on the GPU)
   int max_levels = 12;
 };
 
@@ -263,9 +263,8 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
   const Csr& Ac = H.levels.back().A;
   H.coarse_n = Ac.nrow;
   H.op_complexity = nnz_sum / nnz0;
-  if (H.levels.size() == 1) { H.coarse_n = 0; return true; }  // no coarsening possible: plain Jacobi
-  if (Ac.nrow > 4096) { H.coarse_inv.clear(); return true; }   // too big for a dense inverse: Jacobi sweeps
-  return dense_inverse(Ac, H.coarse_inv);
+  if (H.levels.size() == 1) H.coarse_n = 0;  // no coarsening possible: plain Jacobi
+  return true;                               // the dense inverse of the coarsest operator is formed on the device
 }
 
 }  // namespace amg

@@ -100,7 +100,10 @@ struct hf_ctx {
   int precond = 0;             // 0 Jacobi, 1 smoothed-aggregation AMG V(1,1)
   int amg_reuse = 0;           // 1: keep the coarse levels across hf_assemble calls (kappa sweeps)
   bool amg_ready = false;
-  struct DevCsr { int nrow = 0, ncol = 0, lanes = 8; int64_t nnz = 0; int32_t *ptr = nullptr, *idx = nullptr; double* val = nullptr; };
+  struct DevCsr {
+    int nrow = 0, ncol = 0, lanes = 8; int64_t nnz = 0; int32_t *ptr = nullptr, *idx = nullptr; double* val = nullptr;
+    int rpc = 0, nchunks = 0, chunk_nnz = 0;   // LDS-staged (stream) kernel geometry; rpc = 0 -> use the sub-wave kernel
+  };
   struct DevLevel { DevCsr A, P, R; double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr; double omega = 0; int n = 0; };
   std::vector<DevLevel> amg;
   double* d_coarse_inv = nullptr;
@@ -389,10 +392,15 @@ __global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* 
 //   MODE 3: y = b - A x                                              (multigrid residual)
 //   MODE 4: y = x + w D^-1 (b - A x), partials b.y                   (damped-Jacobi sweep, fused r.z)
 //   MODE 5: y = b - A x; p = w D^-1 y; partials (D^-1 y)^2, (D^-1 b)^2   (AMG-PCG start)
+//   MODE 6: y += A x                                                 (multigrid prolongation)
+//   MODE 7: p = w D^-1 b; y = b - A p   (first Jacobi sweep from zero fused with the residual;
+//           the products gather w*dinv[col]*b[col], so p is never read back)
+// The chunk is `rpc` rows (512 for the fine operator; fewer for long-row transfer operators so
+// that a chunk's products fit the 64-KB LDS window).
 // ------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, const int32_t* __restrict__ rowptr,
-                                              const int32_t* __restrict__ colidx,
+__global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows per chunk, <= TS */,
+                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                               const double* __restrict__ vals, const double* __restrict__ x,
                                               double* __restrict__ y, const Scal* __restrict__ scal,
                                               double* __restrict__ part0, const double* __restrict__ bvec,
@@ -401,15 +409,14 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, const int32_t* 
                                               int npart /* partial slots the consumers sum (>= gridDim.x) */) {
   extern __shared__ double sprod[];
   __shared__ double s4[TS / 64];
-  if ((MODE == 1 || MODE == 3 || MODE == 4) && scal->done) return;
+  if ((MODE == 1 || MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7) && scal->done) return;
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int r0 = chunk * TS;
-    const int r1 = min(n, r0 + TS);
+    const int r0 = chunk * rpc;
+    const int r1 = min(n, r0 + rpc);
     const int k0 = rowptr[r0];
     const int k1 = rowptr[r1];
-#if HF_SPMV_VARIANT == 1      // 4 independent value/index loads and gathers in flight per lane
-    {
+    if (MODE != 7) {  // products in nnz order; 4 independent value/index loads and gathers in flight per lane
       int k = k0 + threadIdx.x;
       for (; k + 3 * TS < k1; k += 4 * TS) {
         const int c0 = colidx[k], c1 = colidx[k + TS], c2 = colidx[k + 2 * TS], c3 = colidx[k + 3 * TS];
@@ -422,25 +429,12 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, const int32_t* 
       }
       for (; k < k1; k += TS) sprod[k - k0] = vals[k] * x[colidx[k]];
     }
-#elif HF_SPMV_VARIANT == 2    // same, matrix streamed with non-temporal loads (read once per launch)
-    {
-      int k = k0 + threadIdx.x;
-      for (; k + 3 * TS < k1; k += 4 * TS) {
-        const int c0 = __builtin_nontemporal_load(&colidx[k]), c1 = __builtin_nontemporal_load(&colidx[k + TS]);
-        const int c2 = __builtin_nontemporal_load(&colidx[k + 2 * TS]), c3 = __builtin_nontemporal_load(&colidx[k + 3 * TS]);
-        const double v0 = __builtin_nontemporal_load(&vals[k]), v1 = __builtin_nontemporal_load(&vals[k + TS]);
-        const double v2 = __builtin_nontemporal_load(&vals[k + 2 * TS]), v3 = __builtin_nontemporal_load(&vals[k + 3 * TS]);
-        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-        sprod[k - k0] = v0 * x0;
-        sprod[k - k0 + TS] = v1 * x1;
-        sprod[k - k0 + 2 * TS] = v2 * x2;
-        sprod[k - k0 + 3 * TS] = v3 * x3;
+    if (MODE == 7) {  // operand is w D^-1 b, formed on the fly
+      for (int k = k0 + threadIdx.x; k < k1; k += TS) {
+        const int c = colidx[k];
+        sprod[k - k0] = vals[k] * (w * dinv[c] * bvec[c]);
       }
-      for (; k < k1; k += TS) sprod[k - k0] = __builtin_nontemporal_load(&vals[k]) * x[__builtin_nontemporal_load(&colidx[k])];
     }
-#else
-    for (int k = k0 + threadIdx.x; k < k1; k += TS) sprod[k - k0] = vals[k] * x[colidx[k]];
-#endif
     __syncthreads();
     const int row = r0 + threadIdx.x;
     if (row < r1) {
@@ -468,19 +462,25 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, const int32_t* 
         const double yi = x[row] + w * dinv[row] * (bi - s);
         y[row] = yi;
         acc0 += bi * yi;
-      } else {
+      } else if (MODE == 5) {
         const double bi = bvec[row], di = dinv[row];
         const double ri = bi - s;
         y[row] = ri;
         pvec[row] = w * di * ri;
         acc1 += (di * ri) * (di * ri);
         acc2 += (di * bi) * (di * bi);
+      } else if (MODE == 6) {
+        y[row] += s;
+      } else {
+        const double bi = bvec[row];
+        pvec[row] = w * dinv[row] * bi;
+        y[row] = bi - s;
       }
     }
     __syncthreads();
   }
   // consumers sum `npart` slots in a fixed order; this launch has fewer workgroups, the rest are zeros
-  if (MODE == 1 || MODE == 2 || MODE == 4) {
+  if (MODE == 1 || MODE == 2 || (MODE == 4 && part0 != nullptr)) {
     const double t0 = block_sum<TS / 64>(acc0, s4);
     if (threadIdx.x == 0) {
       part0[blockIdx.x] = t0;
@@ -578,27 +578,33 @@ __global__ __launch_bounds__(TPB) void k_pcg_dir(int n, int nchunks, int P, int 
 // Generic CSR SpMV for the multigrid transfer operators and coarse levels: LANES lanes of a
 // wavefront share one row (4..64 by the average row length), fixed-order shuffle reduction.
 //   VMODE 0: y = A x      1: y += A x      2: y = b - A x      3: y = x + w D^-1 (b - A x)
+//   VMODE 4: xs = w D^-1 b (stored to xout), y = b - A xs
 // ------------------------------------------------------------------------------------------
 template <int LANES, int VMODE>
 __global__ __launch_bounds__(TPB) void k_spmv_vec(int nrow, const int32_t* __restrict__ ptr,
                                                   const int32_t* __restrict__ idx, const double* __restrict__ val,
                                                   const double* __restrict__ x, double* __restrict__ y,
                                                   const double* __restrict__ b, const double* __restrict__ dinv,
-                                                  double w, const Scal* __restrict__ scal) {
+                                                  double w, const Scal* __restrict__ scal, double* __restrict__ xout) {
   if (scal->done) return;
   const int lane = threadIdx.x % LANES;
   const int rows_per_pass = (gridDim.x * TPB) / LANES;
   for (int row = (blockIdx.x * TPB + threadIdx.x) / LANES; row < nrow; row += rows_per_pass) {
     double s = 0.0;
     const int k1 = ptr[row + 1];
-    for (int k = ptr[row] + lane; k < k1; k += LANES) s += val[k] * x[idx[k]];
+    if (VMODE == 4) {
+      for (int k = ptr[row] + lane; k < k1; k += LANES) { const int c = idx[k]; s += val[k] * (w * dinv[c] * b[c]); }
+    } else {
+      for (int k = ptr[row] + lane; k < k1; k += LANES) s += val[k] * x[idx[k]];
+    }
 #pragma unroll
     for (int o = LANES / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LANES);
     if (lane == 0) {
       if (VMODE == 0) y[row] = s;
       else if (VMODE == 1) y[row] += s;
       else if (VMODE == 2) y[row] = b[row] - s;
-      else y[row] = x[row] + w * dinv[row] * (b[row] - s);
+      else if (VMODE == 3) y[row] = x[row] + w * dinv[row] * (b[row] - s);
+      else { const double bi = b[row]; xout[row] = w * dinv[row] * bi; y[row] = bi - s; }
     }
   }
 }
@@ -624,6 +630,36 @@ __global__ __launch_bounds__(TPB) void k_dense_mv(int n, const double* __restric
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if (lane == 0) x[row] = s;
+  }
+}
+
+
+// Dense inverse of the coarsest operator on the GPU: Gauss-Jordan without pivoting (the operator
+// is SPD, its pivots stay positive).  Two launches per pivot; A is overwritten by the identity.
+__global__ __launch_bounds__(TPB) void k_gj_pivot(int n, int c, const double* __restrict__ A,
+                                                  const double* __restrict__ Inv, double* __restrict__ prow,
+                                                  double* __restrict__ pcol) {
+  const double piv = A[static_cast<size_t>(c) * n + c];
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) {
+    prow[j] = A[static_cast<size_t>(c) * n + j] / piv;
+    prow[n + j] = Inv[static_cast<size_t>(c) * n + j] / piv;
+    pcol[j] = A[static_cast<size_t>(j) * n + c];
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_gj_elim(int n, int c, double* __restrict__ A, double* __restrict__ Inv,
+                                                 const double* __restrict__ prow, const double* __restrict__ pcol) {
+  const size_t total = static_cast<size_t>(n) * n;
+  for (size_t q = static_cast<size_t>(blockIdx.x) * TPB + threadIdx.x; q < total; q += static_cast<size_t>(gridDim.x) * TPB) {
+    const int r = static_cast<int>(q / n), j = static_cast<int>(q % n);
+    if (r == c) {
+      A[q] = prow[j];
+      Inv[q] = prow[n + j];
+    } else {
+      const double f = pcol[r];
+      A[q] -= f * prow[j];
+      Inv[q] -= f * prow[n + j];
+    }
   }
 }
 
@@ -805,7 +841,7 @@ template <int MODE>
 void launch_spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr,
                  const double* bvec = nullptr, double* pvec = nullptr, double* part1 = nullptr,
                  double* part2 = nullptr, double w = 0.0) {
-  hipLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), spmv_smem_bytes(c), c->stream, c->n, c->nchunks_s,
+  hipLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), spmv_smem_bytes(c), c->stream, c->n, c->nchunks_s, TS,
                      c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, c->d_dinv, pvec, part1, part2, w, c->P);
 }
 
@@ -851,6 +887,14 @@ int lanes_for(const amg::Csr& m) {
 
 int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d) {
   d.nrow = h.nrow; d.ncol = h.ncol; d.nnz = h.nnz(); d.lanes = lanes_for(h);
+  d.rpc = 0;
+  if (h.nrow >= 100000) {  // enough 512-row chunks to fill the chip: LDS-staged kernel, chunk products within 64 KB
+    for (int rpc = TS; rpc >= 32; rpc /= 2) {
+      int mx = 0;
+      for (int r0 = 0; r0 < h.nrow; r0 += rpc) mx = std::max(mx, h.ptr[std::min(h.nrow, r0 + rpc)] - h.ptr[r0]);
+      if (mx <= 8000) { d.rpc = rpc; d.nchunks = (h.nrow + rpc - 1) / rpc; d.chunk_nnz = mx; break; }
+    }
+  }
   HF_TRY(dev_alloc(ctx, &d.ptr, h.ptr.size()));
   HF_TRY(dev_alloc(ctx, &d.idx, h.idx.size()));
   HF_TRY(dev_alloc(ctx, &d.val, h.val.size()));
@@ -895,10 +939,33 @@ int build_amg(hf_ctx* ctx) {
     }
     if (l + 1 < nl) { HF_TRY(upload_csr(ctx, hl.P, L.P)); HF_TRY(upload_csr(ctx, hl.R, L.R)); }
   }
-  ctx->coarse_n = static_cast<int>(H.coarse_inv.empty() ? 0 : H.coarse_n);
-  if (ctx->coarse_n > 0) {
-    HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv, H.coarse_inv.size()));
-    HF_HIP(hipMemcpy(ctx->d_coarse_inv, H.coarse_inv.data(), sizeof(double) * H.coarse_inv.size(), hipMemcpyHostToDevice));
+  // coarsest level: dense inverse by Gauss-Jordan on the device
+  ctx->coarse_n = 0;
+  if (nl > 1 && H.coarse_n > 0 && H.coarse_n <= 4096) {
+    const int nc = H.coarse_n;
+    const amg::Csr& Ac = H.levels.back().A;
+    std::vector<double> dense(static_cast<size_t>(nc) * nc, 0.0), eye(static_cast<size_t>(nc) * nc, 0.0);
+    for (int i = 0; i < nc; ++i) {
+      for (int k = Ac.ptr[i]; k < Ac.ptr[i + 1]; ++k) dense[static_cast<size_t>(i) * nc + Ac.idx[k]] = Ac.val[k];
+      eye[static_cast<size_t>(i) * nc + i] = 1.0;
+    }
+    double *d_dense = nullptr, *d_prow = nullptr, *d_pcol = nullptr;
+    HF_TRY(dev_alloc(ctx, &d_dense, dense.size()));
+    HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv, eye.size()));
+    HF_TRY(dev_alloc(ctx, &d_prow, 2 * static_cast<size_t>(nc)));
+    HF_TRY(dev_alloc(ctx, &d_pcol, static_cast<size_t>(nc)));
+    HF_HIP(hipMemcpy(d_dense, dense.data(), sizeof(double) * dense.size(), hipMemcpyHostToDevice));
+    HF_HIP(hipMemcpy(ctx->d_coarse_inv, eye.data(), sizeof(double) * eye.size(), hipMemcpyHostToDevice));
+    const int gp = std::max(1, (nc + TPB - 1) / TPB);
+    const int ge = static_cast<int>(std::min<size_t>((static_cast<size_t>(nc) * nc + TPB - 1) / TPB, 4096));
+    for (int cpiv = 0; cpiv < nc; ++cpiv) {
+      hipLaunchKernelGGL(k_gj_pivot, dim3(gp), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, ctx->d_coarse_inv, d_prow, d_pcol);
+      hipLaunchKernelGGL(k_gj_elim, dim3(ge), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, ctx->d_coarse_inv, d_prow, d_pcol);
+    }
+    HF_HIP(hipGetLastError());
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(&d_dense); dev_free(&d_prow); dev_free(&d_pcol);
+    ctx->coarse_n = nc;
   }
   ctx->amg_opc = H.op_complexity;
   ctx->amg_ready = true;
@@ -906,13 +973,23 @@ int build_amg(hf_ctx* ctx) {
   return HF_OK;
 }
 
+// VMODE 0: y = A x, 1: y += A x, 2: y = b - A x, 3: y = x + w D^-1 (b - A x); LDS-staged kernel when the
+// matrix is big enough to fill the chip, sub-wave kernel otherwise.
 template <int VMODE>
 void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y, const double* b = nullptr,
-                const double* dinv = nullptr, double w = 0.0) {
+                const double* dinv = nullptr, double w = 0.0, double* xout = nullptr) {
+  if (m.rpc > 0) {
+    constexpr int SM = VMODE == 0 ? 0 : VMODE == 1 ? 6 : VMODE == 2 ? 3 : VMODE == 3 ? 4 : 7;
+    const int grid = std::min(m.nchunks, MAXP);
+    hipLaunchKernelGGL(k_spmv<SM>, dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream, m.nrow,
+                       m.nchunks, m.rpc, m.ptr, m.idx, m.val, x, y, c->d_scal, static_cast<double*>(nullptr), b, dinv,
+                       xout, static_cast<double*>(nullptr), static_cast<double*>(nullptr), w, 0);
+    return;
+  }
   const int lanes = m.lanes;
   const long long threads = static_cast<long long>(m.nrow) * lanes;
   const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 2048)));
-#define HF_VEC(L) hipLaunchKernelGGL((k_spmv_vec<L, VMODE>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, m.val, x, y, b, dinv, w, c->d_scal)
+#define HF_VEC(L) hipLaunchKernelGGL((k_spmv_vec<L, VMODE>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, m.val, x, y, b, dinv, w, c->d_scal, xout)
   switch (lanes) {
     case 4: HF_VEC(4); break;
     case 8: HF_VEC(8); break;
@@ -937,9 +1014,7 @@ void vcycle(hf_ctx* c, int out_slot) {
   launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);                                // b1 = R0 t
   for (int l = 1; l + 1 < nl; ++l) {
     DevLevel& L = c->amg[l];
-    const int g = std::max(1, std::min((L.n + TPB - 1) / TPB, 1024));
-    hipLaunchKernelGGL(k_scale, dim3(g), dim3(TPB), 0, c->stream, L.n, L.omega, L.dinv, L.b, L.x, c->d_scal);
-    launch_vec<2>(c, L.A, L.x, L.r, L.b);                                       // r_l = b_l - A_l x_l
+    launch_vec<4>(c, L.A, L.b, L.r, L.b, L.dinv, L.omega, L.x);                 // x_l = w D^-1 b_l ; r_l = b_l - A_l x_l
     launch_vec<0>(c, L.R, L.r, c->amg[l + 1].b);                                // b_{l+1} = R_l r_l
   }
   {
