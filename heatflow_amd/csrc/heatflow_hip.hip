@@ -74,7 +74,8 @@ struct hf_ctx {
   double *d_kappa = nullptr, *d_rhoc = nullptr;
   // device: pattern + owner lists
   int32_t *d_rowptr = nullptr, *d_colidx = nullptr;
-  int32_t *d_blk_eptr = nullptr, *d_blk_cptr = nullptr, *d_blk_elist = nullptr;
+  int32_t *d_blk_eptr = nullptr, *d_blk_cptr = nullptr;
+  int4 *d_blk_ent = nullptr, *d_blk_el = nullptr;
   int max_blk_nnz = 0, ncolors = 0;
   int64_t elist_len = 0;
   // device: matrices
@@ -185,6 +186,10 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ part, 
 // m[] / k[] hold the symmetric 3x3 as {00, 11, 22, 01, 02, 12}.
 __device__ __forceinline__ void element_local(const double2 p0, const double2 p1, const double2 p2, double rho_c,
                                               double kappa, double m[6], double k[6]) {
+  // No FMA contraction here: the same element is evaluated by different workgroups (and by
+  // different unrolled copies of the caller); every evaluation must give the same bits so that the
+  // assembled matrices stay exactly symmetric.
+#pragma clang fp contract(off)
   const double d = (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
   const double area = 0.5 * fabs(d);
   const double b0 = p1.y - p2.y, b1 = p2.y - p0.y, b2 = p0.y - p1.y;
@@ -221,19 +226,17 @@ __device__ __forceinline__ int sym_index(int a, int b) {  // (a,b) -> slot in {0
 // ------------------------------------------------------------------------------------------
 template <bool COLORED>
 __global__ __launch_bounds__(TPB) void k_assemble_lds(int n, int cap, const int32_t* __restrict__ rowptr,
-                                                      const int32_t* __restrict__ colidx,
                                                       const int32_t* __restrict__ blk_eptr,
                                                       const int32_t* __restrict__ blk_cptr,
-                                                      const int32_t* __restrict__ blk_elist,
-                                                      const int4* __restrict__ elem, const double2* __restrict__ zr,
+                                                      const int4* __restrict__ blk_ent,
+                                                      const int4* __restrict__ blk_el, const double2* __restrict__ zr,
                                                       const double* __restrict__ kappa_tab,
                                                       const double* __restrict__ rhoc_tab, double dt,
                                                       double* __restrict__ Mv, double* __restrict__ Av) {
   extern __shared__ double smem[];
   double* sM = smem;
   double* sA = smem + cap;
-  int* sC = reinterpret_cast<int*>(smem + 2 * cap);
-  int* sR = sC + cap;
+  int* sR = reinterpret_cast<int*>(smem + 2 * cap);
 
   const int blk = blockIdx.x;
   const int r0 = blk * RB;
@@ -243,37 +246,61 @@ __global__ __launch_bounds__(TPB) void k_assemble_lds(int n, int cap, const int3
   for (int k = threadIdx.x; k < nk; k += TPB) {
     sM[k] = 0.0;
     sA[k] = 0.0;
-    sC[k] = colidx[k0 + k];
   }
   for (int k = threadIdx.x; k <= r1 - r0; k += TPB) sR[k] = rowptr[r0 + k] - k0;
   __syncthreads();
 
-  auto process = [&](int e) {
-    const int4 el = elem[e];
+  // One list entry = (element id, nine slot offsets inside the rows of its three nodes, ownership
+  // mask): x = element, y|z|w[7:0] = offsets of (a,b) = (0,0) (0,1) ... (2,2), w[10:8] = node a owned.
+  auto scatter = [&](const int4 ent, const int4 el, const double2 p0, const double2 p1, const double2 p2) {
+    double m[6], kk[6], av6[6];
+    element_local(p0, p1, p2, rhoc_tab[el.w], kappa_tab[el.w], m, kk);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) av6[q] = fma(dt, kk[q], m[q]);  // once per unique entry, explicit FMA: same bits everywhere
     const int nd[3] = {el.x, el.y, el.z};
-    double m[6], kk[6];
-    element_local(zr[el.x], zr[el.y], zr[el.z], rhoc_tab[el.w], kappa_tab[el.w], m, kk);
+    const unsigned pos03 = static_cast<unsigned>(ent.y), pos47 = static_cast<unsigned>(ent.z);
+    const unsigned pos8 = static_cast<unsigned>(ent.w);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const int row = nd[a];
-      if (row < r0 || row >= r1) continue;
-      const int s0 = sR[row - r0], s1 = sR[row - r0 + 1];
+      if (!((pos8 >> (8 + a)) & 1u)) continue;
+      const int base = sR[nd[a] - r0];
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        const int col = nd[b];
-        int s = s0;
-        while (s < s1 && sC[s] != col) ++s;     // rows hold <= ~12 entries
+        const int q9 = a * 3 + b;
+        const unsigned off = q9 < 4 ? (pos03 >> (8 * q9)) & 0xFFu : q9 < 8 ? (pos47 >> (8 * (q9 - 4))) & 0xFFu : pos8 & 0xFFu;
+        const int slot = base + static_cast<int>(off);
         const int q = sym_index(a, b);
         const double mv = m[q];
-        const double av = mv + dt * kk[q];
+        const double av = av6[q];
         if (COLORED) {
-          sM[s] += mv;
-          sA[s] += av;
+          sM[slot] += mv;
+          sA[slot] += av;
         } else {
-          atomicAdd(&sM[s], mv);
-          atomicAdd(&sA[s], av);
+          atomicAdd(&sM[slot], mv);
+          atomicAdd(&sA[slot], av);
         }
       }
+    }
+  };
+  // The list is laid out per workgroup: entry q = (offsets/mask, blk_ent[q]) + a copy of its element
+  // record (n0, n1, n2, tag; blk_el[q]) - both streamed coalesced, only the coordinates are gathered.
+  // Three elements in flight per lane: all loads are issued before the first scatter.
+  constexpr int NF = 3;
+  auto run_range = [&](int e0, int e1) {
+    for (int k = e0 + threadIdx.x; k < e1; k += NF * TPB) {
+      int4 ent[NF], el[NF];
+      double2 pa[NF], pb[NF], pc[NF];
+#pragma unroll
+      for (int u = 0; u < NF; ++u) {
+        const int q = min(k + u * TPB, e1 - 1);
+        ent[u] = blk_ent[q];
+        el[u] = blk_el[q];
+      }
+#pragma unroll
+      for (int u = 0; u < NF; ++u) { pa[u] = zr[el[u].x]; pb[u] = zr[el[u].y]; pc[u] = zr[el[u].z]; }
+#pragma unroll
+      for (int u = 0; u < NF; ++u)
+        if (k + u * TPB < e1) scatter(ent[u], el[u], pa[u], pb[u], pc[u]);
     }
   };
 
@@ -282,12 +309,11 @@ __global__ __launch_bounds__(TPB) void k_assemble_lds(int n, int cap, const int3
     for (int c = 0; c < NCOL; ++c) {
       const int e0 = cp[c], e1 = cp[c + 1];
       if (e0 == e1) { if (e1 == cp[NCOL]) break; else continue; }
-      for (int k = e0 + threadIdx.x; k < e1; k += TPB) process(blk_elist[k]);
+      run_range(e0, e1);
       __syncthreads();
     }
   } else {
-    const int e0 = blk_eptr[blk], e1 = blk_eptr[blk + 1];
-    for (int k = e0 + threadIdx.x; k < e1; k += TPB) process(blk_elist[k]);
+    run_range(blk_eptr[blk], blk_eptr[blk + 1]);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < nk; k += TPB) {
@@ -308,8 +334,10 @@ __global__ __launch_bounds__(TPB) void k_assemble_global(int ne, const int32_t* 
   if (e >= ne) return;
   const int4 el = elem[e];
   const int nd[3] = {el.x, el.y, el.z};
-  double m[6], kk[6];
+  double m[6], kk[6], av6[6];
   element_local(zr[el.x], zr[el.y], zr[el.z], rhoc_tab[el.w], kappa_tab[el.w], m, kk);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) av6[q] = fma(dt, kk[q], m[q]);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int s0 = rowptr[nd[a]], s1 = rowptr[nd[a] + 1];
@@ -319,7 +347,7 @@ __global__ __launch_bounds__(TPB) void k_assemble_global(int ne, const int32_t* 
       while (s < s1 && colidx[s] != nd[b]) ++s;
       const int q = sym_index(a, b);
       atomicAdd(&Mv[s], m[q]);
-      atomicAdd(&Av[s], m[q] + dt * kk[q]);
+      atomicAdd(&Av[s], av6[q]);
     }
   }
 }
@@ -728,10 +756,12 @@ __global__ __launch_bounds__(TPB) void k_pcg_dir_amg(int n, int nchunks, int P, 
 // ------------------------------------------------------------------------------------------
 struct Pattern {
   std::vector<int32_t> rowptr, colidx, blk_eptr, blk_cptr, blk_elist;
+  std::vector<int4> blk_ent;       // blk_elist entries widened with the nine slot offsets + ownership mask
+  std::vector<int4> blk_el;        // (n0, n1, n2, tag) of the same entries: a per-workgroup copy of the element records
   int max_blk_nnz = 0, ncolors = 0;
 };
 
-int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, Pattern& P) {
+int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const int32_t* tag, Pattern& P) {
   std::vector<int32_t> nptr(static_cast<size_t>(n) + 1, 0);
   for (int64_t k = 0; k < 3LL * ne; ++k) nptr[tri[k] + 1]++;
   for (int32_t i = 0; i < n; ++i) nptr[i + 1] += nptr[i];
@@ -809,6 +839,32 @@ int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, Patter
     P.blk_eptr[b] = base;
     P.blk_eptr[b + 1] = static_cast<int32_t>(P.blk_elist.size());
   }
+  // widen every list entry with the offsets of its nine contributions inside the CSR rows
+  P.blk_ent.resize(P.blk_elist.size());
+  P.blk_el.resize(P.blk_elist.size());
+  for (int b = 0; b < nblk; ++b) {
+    const int32_t r0 = b * RB, r1 = std::min<int32_t>(n, r0 + RB);
+    for (int32_t q = P.blk_eptr[b]; q < P.blk_eptr[b + 1]; ++q) {
+      const int32_t e = P.blk_elist[q];
+      const int32_t nd[3] = {tri[3 * e], tri[3 * e + 1], tri[3 * e + 2]};
+      uint32_t pos[9] = {0}, owned = 0;
+      for (int a = 0; a < 3; ++a) {
+        if (nd[a] < r0 || nd[a] >= r1) continue;
+        owned |= 1u << a;
+        const int32_t* rb = &P.colidx[P.rowptr[nd[a]]];
+        const int32_t* re = &P.colidx[P.rowptr[nd[a] + 1]];
+        if (re - rb > 255) return fail(ctx, HF_ERR_ARG, "row %d holds more than 255 entries", nd[a]);
+        for (int c = 0; c < 3; ++c) pos[a * 3 + c] = static_cast<uint32_t>(std::lower_bound(rb, re, nd[c]) - rb);
+      }
+      int4 ent;
+      ent.x = e;
+      ent.y = static_cast<int>(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24));
+      ent.z = static_cast<int>(pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24));
+      ent.w = static_cast<int>(pos[8] | (owned << 8));
+      P.blk_ent[q] = ent;
+      P.blk_el[q] = make_int4(nd[0], nd[1], nd[2], tag[e]);
+    }
+  }
   return HF_OK;
 }
 
@@ -816,15 +872,15 @@ size_t spmv_smem_bytes(const hf_ctx* c) { return static_cast<size_t>(c->max_chun
 
 int launch_assemble(hf_ctx* ctx) {
   const int nblk = ctx->nchunks;
-  const int cap = (ctx->max_blk_nnz + 1) & ~1;  // keep the int arrays 8-byte aligned
-  const size_t sm = static_cast<size_t>(cap) * 20 + (RB + 1) * 4;
+  const int cap = (ctx->max_blk_nnz + 1) & ~1;  // keep the int array 8-byte aligned
+  const size_t sm = static_cast<size_t>(cap) * 16 + (RB + 1) * 4;
   if (ctx->mode == HF_ASM_LDS_COLORED) {
     hipLaunchKernelGGL(k_assemble_lds<true>, dim3(nblk), dim3(TPB), sm, ctx->stream, ctx->n, cap, ctx->d_rowptr,
-                       ctx->d_colidx, ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_elist, ctx->d_elem, ctx->d_zr,
+                       ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_blk_el, ctx->d_zr,
                        ctx->d_kappa, ctx->d_rhoc, ctx->dt, ctx->d_M, ctx->d_A);
   } else if (ctx->mode == HF_ASM_LDS_ATOMIC) {
     hipLaunchKernelGGL(k_assemble_lds<false>, dim3(nblk), dim3(TPB), sm, ctx->stream, ctx->n, cap, ctx->d_rowptr,
-                       ctx->d_colidx, ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_elist, ctx->d_elem, ctx->d_zr,
+                       ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_blk_el, ctx->d_zr,
                        ctx->d_kappa, ctx->d_rhoc, ctx->dt, ctx->d_M, ctx->d_A);
   } else {
     HF_HIP(hipMemsetAsync(ctx->d_M, 0, sizeof(double) * ctx->nnz, ctx->stream));
@@ -1223,8 +1279,7 @@ int hf_destroy(hf_ctx* ctx) {
   (void)hipSetDevice(ctx->dev);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   dev_free(&ctx->d_zr); dev_free(&ctx->d_elem); dev_free(&ctx->d_kappa); dev_free(&ctx->d_rhoc);
-  dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr);
-  dev_free(&ctx->d_blk_elist); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
+  dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent); dev_free(&ctx->d_blk_el); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
   dev_free(&ctx->d_bc_dofs); dev_free(&ctx->d_g); dev_free(&ctx->d_lift_rows); dev_free(&ctx->d_lift_ptr);
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_u); dev_free(&ctx->d_b); dev_free(&ctx->d_r); dev_free(&ctx->d_p); dev_free(&ctx->d_Ap);
@@ -1255,7 +1310,7 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
     if (!(d != 0.0)) return fail(ctx, HF_ERR_ARG, "hf_set_mesh: degenerate triangle %d", e);
   }
   Pattern P;
-  HF_TRY(build_pattern(ctx, n, ne, tri, P));
+  HF_TRY(build_pattern(ctx, n, ne, tri, tag, P));
   ctx->n = n; ctx->ne = ne; ctx->nnz = static_cast<int64_t>(P.colidx.size());
   ctx->nchunks = (n + RB - 1) / RB;
   ctx->P = std::min(ctx->nchunks, MAXP);
@@ -1267,7 +1322,7 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   ctx->max_blk_nnz = P.max_blk_nnz;
   ctx->ncolors = P.ncolors;
   ctx->elist_len = static_cast<int64_t>(P.blk_elist.size());
-  if (static_cast<size_t>((ctx->max_blk_nnz + 1) & ~1) * 20 + (RB + 1) * 4 > 160 * 1024)
+  if (static_cast<size_t>((ctx->max_blk_nnz + 1) & ~1) * 16 + (RB + 1) * 4 > 64 * 1024)
     return fail(ctx, HF_ERR_ARG, "row block holds %d nonzeros: LDS slab too large", ctx->max_blk_nnz);
   ctx->tab_len = maxtag + 1;
   ctx->h_tag_used.assign(ctx->tab_len, 0);
@@ -1284,7 +1339,8 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_TRY(dev_alloc(ctx, &ctx->d_colidx, ctx->nnz));
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_eptr, P.blk_eptr.size()));
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_cptr, P.blk_cptr.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_blk_elist, P.blk_elist.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_blk_ent, P.blk_ent.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_blk_el, P.blk_el.size()));
   HF_TRY(dev_alloc(ctx, &ctx->d_M, ctx->nnz));
   HF_TRY(dev_alloc(ctx, &ctx->d_A, ctx->nnz));
   HF_TRY(dev_alloc(ctx, &ctx->d_dinv, n));
@@ -1303,7 +1359,8 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_HIP(hipMemcpy(ctx->d_colidx, P.colidx.data(), sizeof(int32_t) * ctx->nnz, hipMemcpyHostToDevice));
   HF_HIP(hipMemcpy(ctx->d_blk_eptr, P.blk_eptr.data(), sizeof(int32_t) * P.blk_eptr.size(), hipMemcpyHostToDevice));
   HF_HIP(hipMemcpy(ctx->d_blk_cptr, P.blk_cptr.data(), sizeof(int32_t) * P.blk_cptr.size(), hipMemcpyHostToDevice));
-  HF_HIP(hipMemcpy(ctx->d_blk_elist, P.blk_elist.data(), sizeof(int32_t) * P.blk_elist.size(), hipMemcpyHostToDevice));
+  HF_HIP(hipMemcpy(ctx->d_blk_ent, P.blk_ent.data(), sizeof(int4) * P.blk_ent.size(), hipMemcpyHostToDevice));
+  HF_HIP(hipMemcpy(ctx->d_blk_el, P.blk_el.data(), sizeof(int4) * P.blk_el.size(), hipMemcpyHostToDevice));
   HF_HIP(hipMemset(ctx->d_u, 0, sizeof(double) * n));
   ctx->h_rowptr.swap(P.rowptr);
   ctx->h_colidx.swap(P.colidx);
