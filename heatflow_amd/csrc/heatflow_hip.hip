@@ -111,6 +111,10 @@ struct hf_ctx {
   int coarse_n = 0;
   double amg_opc = 0.0, amg_setup_s = 0.0;
   double *d_z = nullptr, *d_z2 = nullptr;
+  // read-flux projection (hf_flux_setup): unit-rho_c r-weighted mass matrix and the projected gradient
+  bool flux_ready = false;
+  double *d_M1 = nullptr, *d_dinv1 = nullptr, *d_gz = nullptr, *d_gr = nullptr, *d_bz = nullptr, *d_br = nullptr;
+  int pred_flux[2] = {0, 0};
   // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
@@ -349,6 +353,52 @@ __global__ __launch_bounds__(TPB) void k_assemble_global(int ne, const int32_t* 
       atomicAdd(&Mv[s], m[q]);
       atomicAdd(&Av[s], av6[q]);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Read-flux projection (reference run_no_diamond.py:479-489, 544-550): L2 projection of grad T
+// onto vector P1 with the r-weighted mass matrix.  The reference solves one 2n x 2n system; the
+// components decouple into two scalar solves with M_r(1).  This kernel forms both right-hand
+// sides  b_c[i] = sum_e (d_c T)_e * int_e phi_i r dx,  int_e phi_i r = |K| (2 r_i + r_j + r_k)/12,
+// owner-computes like the assembly: a workgroup owns 256 rows and adds the incident elements.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_grad_rhs(int n, const int32_t* __restrict__ blk_eptr,
+                                                  const int4* __restrict__ blk_ent, const int4* __restrict__ blk_el,
+                                                  const double2* __restrict__ zr, const double* __restrict__ u,
+                                                  double* __restrict__ bz, double* __restrict__ br) {
+  __shared__ double sB[2 * RB];
+  const int blk = blockIdx.x;
+  const int r0 = blk * RB;
+  const int r1 = min(n, r0 + RB);
+  for (int k = threadIdx.x; k < 2 * RB; k += TPB) sB[k] = 0.0;
+  __syncthreads();
+  for (int q = blk_eptr[blk] + threadIdx.x; q < blk_eptr[blk + 1]; q += TPB) {
+#pragma clang fp contract(off)
+    const int4 ent = blk_ent[q];
+    const int4 el = blk_el[q];
+    const double2 p0 = zr[el.x], p1 = zr[el.y], p2 = zr[el.z];
+    const double u0 = u[el.x], u1 = u[el.y], u2 = u[el.z];
+    const double d = (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+    const double area = 0.5 * fabs(d);
+    // grad phi_i = (b_i, c_i)/d
+    const double gz = (u0 * (p1.y - p2.y) + u1 * (p2.y - p0.y) + u2 * (p0.y - p1.y)) / d;
+    const double gr = (u0 * (p2.x - p1.x) + u1 * (p0.x - p2.x) + u2 * (p1.x - p0.x)) / d;
+    const double rsum = (p0.y + p1.y) + p2.y;
+    const double wgt[3] = {area * (p0.y + rsum) / 12.0, area * (p1.y + rsum) / 12.0, area * (p2.y + rsum) / 12.0};
+    const int nd[3] = {el.x, el.y, el.z};
+    const unsigned owned = (static_cast<unsigned>(ent.w) >> 8) & 7u;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (!((owned >> a) & 1u)) continue;
+      atomicAdd(&sB[2 * (nd[a] - r0)], gz * wgt[a]);
+      atomicAdd(&sB[2 * (nd[a] - r0) + 1], gr * wgt[a]);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < r1 - r0; k += TPB) {
+    bz[r0 + k] = sB[2 * k];
+    br[r0 + k] = sB[2 * k + 1];
   }
 }
 
@@ -896,22 +946,26 @@ int launch_assemble(hf_ctx* ctx) {
 template <int MODE>
 void launch_spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr,
                  const double* bvec = nullptr, double* pvec = nullptr, double* part1 = nullptr,
-                 double* part2 = nullptr, double w = 0.0) {
+                 double* part2 = nullptr, double w = 0.0, const double* dinv = nullptr) {
   hipLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), spmv_smem_bytes(c), c->stream, c->n, c->nchunks_s, TS,
-                     c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, c->d_dinv, pvec, part1, part2, w, c->P);
+                     c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, dinv ? dinv : c->d_dinv, pvec, part1,
+                     part2, w, c->P);
 }
 
 constexpr int PROF_PAIRS = 64;
 
-void launch_pcg_iteration(hf_ctx* c, int parity) {
+// A linear system on the context's sparsity pattern: values, inverse diagonal, unknown, right-hand side.
+struct LinSys { const double* A; const double* dinv; double* x; const double* b; };
+
+void launch_pcg_iteration(hf_ctx* c, const LinSys& s, int parity) {
   const bool timed = c->prof && c->prof_used < PROF_PAIRS;
   if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_used], c->stream);
-  launch_spmv<1>(c, c->d_A, c->d_p, c->d_Ap, c->d_part_pAp);
+  launch_spmv<1>(c, s.A, c->d_p, c->d_Ap, c->d_part_pAp);
   if (timed) { (void)hipEventRecord(c->prof_ev[2 * c->prof_used + 1], c->stream); c->prof_used++; }
   hipLaunchKernelGGL(k_pcg_update, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
-                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, c->d_u, c->d_r, c->d_p, c->d_Ap, c->d_dinv);
+                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, s.x, c->d_r, c->d_p, c->d_Ap, s.dinv);
   hipLaunchKernelGGL(k_pcg_dir, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
-                     c->d_part_rz, c->d_part_zz, c->d_r, c->d_p, c->d_dinv);
+                     c->d_part_rz, c->d_part_zz, c->d_r, c->d_p, s.dinv);
 }
 
 
@@ -1124,6 +1178,58 @@ int read_scal(hf_ctx* ctx) {
   return HF_OK;
 }
 
+// PCG on `sys` started from sys.x.  Jacobi: any system on the pattern; AMG: the main system only.
+// Iteration count / residual are left in h_scal; *pred carries the burst-size hint between calls.
+int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double atol, int max_it, int* pred) {
+  if (!use_amg) {
+    // r = b - A x, p = z = D^-1 r
+    launch_spmv<2>(ctx, sys.A, sys.x, ctx->d_r, ctx->d_part_rz, sys.b, ctx->d_p, ctx->d_part_zz, ctx->d_part_bn, 0.0,
+                   sys.dinv);
+    hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
+                       ctx->d_part_bn, ctx->d_scal);
+  } else {
+    // r = b - A x, z0 = w D^-1 r; tolerance; z = B r (V-cycle, r.z into slot 0); p = z
+    HF_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(Scal), ctx->stream));   // done = 0 so the start kernels run
+    launch_spmv<5>(ctx, sys.A, sys.x, ctx->d_r, nullptr, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn,
+                   ctx->amg[0].omega);
+    hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
+                       ctx->d_part_bn, ctx->d_scal);
+    vcycle(ctx, 0);
+    hipLaunchKernelGGL(k_pcg_dir_amg, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, ctx->nchunks, ctx->P, 0, 1,
+                       ctx->d_scal, ctx->d_part_rz, ctx->d_part_zz, ctx->d_z, ctx->d_p);
+  }
+  HF_HIP(hipGetLastError());
+
+  int launched = 0;
+  if (*pred <= 0) {  // previous solve needed no iteration (e.g. constant field): look before launching
+    HF_TRY(read_scal(ctx));
+    if (ctx->h_scal->done == 1) return HF_OK;
+  }
+  // first burst: what the previous solve needed (the counts drift slowly), then check in small bursts
+  int burst = std::max(2, std::min(max_it, *pred > 0 ? *pred : (use_amg ? 8 : 32)));
+  while (true) {
+    burst += burst & 1;  // parity pairs
+    ctx->prof_base = launched;
+    for (int k = 0; k < burst; ++k) {
+      if (use_amg) launch_amg_iteration(ctx, (launched + k) & 1);
+      else launch_pcg_iteration(ctx, sys, (launched + k) & 1);
+    }
+    launched += burst;
+    HF_HIP(hipGetLastError());
+    HF_TRY(read_scal(ctx));
+    if (ctx->h_scal->done) break;
+    if (launched >= max_it) break;
+    burst = std::min(std::max(use_amg ? 2 : 8, launched / 8), max_it - launched);
+    burst = std::max(burst, 2);
+  }
+  *pred = ctx->h_scal->iters;
+  if (ctx->h_scal->done == 2) return fail(ctx, HF_ERR_NOCONV, "PCG breakdown (p.Ap <= 0) after %d iterations", ctx->h_scal->iters);
+  if (!ctx->h_scal->done)
+    return fail(ctx, HF_ERR_NOCONV, "PCG not converged in %d iterations (rel. residual %.3e)", ctx->h_scal->iters,
+                std::sqrt(ctx->h_scal->zz / std::max(ctx->h_scal->bn2, 1e-300)));
+  return HF_OK;
+}
+
 // One time step with g already in d_g.  Leaves iteration count / residual in h_scal.
 int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
   const int nb = ctx->nbc;
@@ -1137,54 +1243,8 @@ int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
     hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, ctx->d_g,
                        ctx->d_b, ctx->d_u);
   }
-  const bool use_amg = ctx->precond == 1 && ctx->amg_ready;
-  if (!use_amg) {
-    // r = b - A u, p = z = D^-1 r
-    launch_spmv<2>(ctx, ctx->d_A, ctx->d_u, ctx->d_r, ctx->d_part_rz, ctx->d_b, ctx->d_p, ctx->d_part_zz,
-                   ctx->d_part_bn);
-    hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
-                       ctx->d_part_bn, ctx->d_scal);
-  } else {
-    // r = b - A u, z0 = w D^-1 r; tolerance; z = B r (V-cycle, r.z into slot 0); p = z
-    HF_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(Scal), ctx->stream));   // done = 0 so the start kernels run
-    launch_spmv<5>(ctx, ctx->d_A, ctx->d_u, ctx->d_r, nullptr, ctx->d_b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn,
-                   ctx->amg[0].omega);
-    hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
-                       ctx->d_part_bn, ctx->d_scal);
-    vcycle(ctx, 0);
-    hipLaunchKernelGGL(k_pcg_dir_amg, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, ctx->nchunks, ctx->P, 0, 1,
-                       ctx->d_scal, ctx->d_part_rz, ctx->d_part_zz, ctx->d_z, ctx->d_p);
-  }
-  HF_HIP(hipGetLastError());
-
-  int launched = 0;
-  if (ctx->pred_iters <= 0) {  // previous step needed no iteration (e.g. constant field): look before launching
-    HF_TRY(read_scal(ctx));
-    if (ctx->h_scal->done == 1) return HF_OK;
-  }
-  // first burst: what the previous step needed (the counts drift slowly), then check in small bursts
-  int burst = std::max(2, std::min(max_it, ctx->pred_iters > 0 ? ctx->pred_iters : (use_amg ? 8 : 32)));
-  while (true) {
-    burst += burst & 1;  // parity pairs
-    ctx->prof_base = launched;
-    for (int k = 0; k < burst; ++k) {
-      if (use_amg) launch_amg_iteration(ctx, (launched + k) & 1);
-      else launch_pcg_iteration(ctx, (launched + k) & 1);
-    }
-    launched += burst;
-    HF_HIP(hipGetLastError());
-    HF_TRY(read_scal(ctx));
-    if (ctx->h_scal->done) break;
-    if (launched >= max_it) break;
-    burst = std::min(std::max(use_amg ? 2 : 8, launched / 8), max_it - launched);
-    burst = std::max(burst, 2);
-  }
-  ctx->pred_iters = ctx->h_scal->iters;
-  if (ctx->h_scal->done == 2) return fail(ctx, HF_ERR_NOCONV, "PCG breakdown (p.Ap <= 0) after %d iterations", ctx->h_scal->iters);
-  if (!ctx->h_scal->done)
-    return fail(ctx, HF_ERR_NOCONV, "PCG not converged in %d iterations (rel. residual %.3e)", ctx->h_scal->iters,
-                std::sqrt(ctx->h_scal->zz / std::max(ctx->h_scal->bn2, 1e-300)));
-  return HF_OK;
+  const LinSys sys{ctx->d_A, ctx->d_dinv, ctx->d_u, ctx->d_b};
+  return pcg_solve(ctx, sys, ctx->precond == 1 && ctx->amg_ready, rtol, atol, max_it, &ctx->pred_iters);
 }
 
 int ensure_samples(hf_ctx* ctx, int ns) {
@@ -1284,6 +1344,7 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_u); dev_free(&ctx->d_b); dev_free(&ctx->d_r); dev_free(&ctx->d_p); dev_free(&ctx->d_Ap);
   free_amg(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
+  dev_free(&ctx->d_M1); dev_free(&ctx->d_dinv1); dev_free(&ctx->d_gz); dev_free(&ctx->d_gr); dev_free(&ctx->d_bz); dev_free(&ctx->d_br);
   dev_free(&ctx->d_tmp); dev_free(&ctx->d_part_pAp); dev_free(&ctx->d_part_rz); dev_free(&ctx->d_part_zz);
   dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp);
   for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -1368,6 +1429,7 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   ctx->nbc = 0; ctx->nlift = 0; ctx->nlift_rows = 0;
   ctx->have_mesh = true;
   ctx->pred_iters = 0;
+  ctx->flux_ready = false;
   return HF_OK;
 }
 
@@ -1467,6 +1529,66 @@ int hf_get_amg_info(hf_ctx* ctx, int32_t* n_levels, int32_t* level_rows, int32_t
     for (int l = 0; l < nl && l < max_levels; ++l) level_rows[l] = ctx->amg[l].n;
   if (op_complexity) *op_complexity = ctx->amg_ready ? ctx->amg_opc : 0.0;
   if (setup_seconds) *setup_seconds = ctx->amg_ready ? ctx->amg_setup_s : 0.0;
+  return HF_OK;
+}
+
+int hf_flux_setup(hf_ctx* ctx) {
+  if (!ctx) return HF_ERR_ARG;
+  if (!ctx->have_mesh) return fail(ctx, HF_ERR_STATE, "hf_flux_setup before hf_set_mesh");
+  HF_HIP(hipSetDevice(ctx->dev));
+  const int n = ctx->n;
+  HF_TRY(dev_alloc(ctx, &ctx->d_M1, ctx->nnz));
+  HF_TRY(dev_alloc(ctx, &ctx->d_dinv1, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_gz, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_gr, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_bz, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_br, n));
+  // M_r(1): the element kernel with rho_c = 1, kappa = 0, dt = 0 (its A output = M goes to scratch)
+  double *d_one = nullptr, *d_zero = nullptr, *d_scratch = nullptr;
+  HF_TRY(dev_alloc(ctx, &d_one, ctx->tab_len));
+  HF_TRY(dev_alloc(ctx, &d_zero, ctx->tab_len));
+  HF_TRY(dev_alloc(ctx, &d_scratch, ctx->nnz));
+  std::vector<double> ones(ctx->tab_len, 1.0), zeros(ctx->tab_len, 0.0);
+  HF_HIP(hipMemcpy(d_one, ones.data(), sizeof(double) * ctx->tab_len, hipMemcpyHostToDevice));
+  HF_HIP(hipMemcpy(d_zero, zeros.data(), sizeof(double) * ctx->tab_len, hipMemcpyHostToDevice));
+  const int cap = (ctx->max_blk_nnz + 1) & ~1;
+  const size_t sm = static_cast<size_t>(cap) * 16 + (RB + 1) * 4;
+  hipLaunchKernelGGL(k_assemble_lds<true>, dim3(ctx->nchunks), dim3(TPB), sm, ctx->stream, n, cap, ctx->d_rowptr,
+                     ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_blk_el, ctx->d_zr, d_zero, d_one, 0.0,
+                     ctx->d_M1, d_scratch);
+  hipLaunchKernelGGL(k_dinv, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ctx->d_rowptr, ctx->d_colidx,
+                     ctx->d_M1, ctx->d_dinv1);
+  HF_HIP(hipMemsetAsync(ctx->d_gz, 0, sizeof(double) * n, ctx->stream));
+  HF_HIP(hipMemsetAsync(ctx->d_gr, 0, sizeof(double) * n, ctx->stream));
+  HF_HIP(hipGetLastError());
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  dev_free(&d_one); dev_free(&d_zero); dev_free(&d_scratch);
+  ctx->flux_ready = true;
+  ctx->pred_flux[0] = ctx->pred_flux[1] = 0;
+  return HF_OK;
+}
+
+int hf_flux_project(hf_ctx* ctx, double rtol, int32_t max_it, double* grad_z, double* grad_r, int32_t* iters) {
+  if (!ctx) return HF_ERR_ARG;
+  if (!ctx->flux_ready) return fail(ctx, HF_ERR_STATE, "hf_flux_project before hf_flux_setup");
+  if (max_it <= 0 || rtol < 0) return fail(ctx, HF_ERR_ARG, "hf_flux_project: bad tolerances");
+  HF_HIP(hipSetDevice(ctx->dev));
+  const int n = ctx->n;
+  hipLaunchKernelGGL(k_grad_rhs, dim3(ctx->nchunks), dim3(TPB), 0, ctx->stream, n, ctx->d_blk_eptr, ctx->d_blk_ent,
+                     ctx->d_blk_el, ctx->d_zr, ctx->d_u, ctx->d_bz, ctx->d_br);
+  HF_HIP(hipGetLastError());
+  // two scalar mass-matrix solves, each warm-started from the previous projection
+  const LinSys sz{ctx->d_M1, ctx->d_dinv1, ctx->d_gz, ctx->d_bz};
+  int rc = pcg_solve(ctx, sz, false, rtol, 0.0, max_it, &ctx->pred_flux[0]);
+  if (iters) iters[0] = ctx->h_scal->iters;
+  if (rc != HF_OK) return rc;
+  const LinSys sr{ctx->d_M1, ctx->d_dinv1, ctx->d_gr, ctx->d_br};
+  rc = pcg_solve(ctx, sr, false, rtol, 0.0, max_it, &ctx->pred_flux[1]);
+  if (iters) iters[1] = ctx->h_scal->iters;
+  if (rc != HF_OK) return rc;
+  if (grad_z) HF_HIP(hipMemcpyAsync(grad_z, ctx->d_gz, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (grad_r) HF_HIP(hipMemcpyAsync(grad_r, ctx->d_gr, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HF_HIP(hipStreamSynchronize(ctx->stream));
   return HF_OK;
 }
 

@@ -100,13 +100,14 @@ class SimulationSession:
     """
 
     def __init__(self, coords, tris, tags, material_tags, *, device_id=0, backend=None, rtol=DEFAULT_RTOL,
-                 max_it=DEFAULT_MAX_IT, assembly_mode=0):
+                 max_it=DEFAULT_MAX_IT, assembly_mode=0, precond=1):
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.tris = np.ascontiguousarray(tris, dtype=np.int32)
         self.tags = np.ascontiguousarray(tags, dtype=np.int32)
         self.material_tags = dict(material_tags)
         self.device_id, self.backend = device_id, backend
         self.rtol, self.max_it, self.assembly_mode = rtol, max_it, assembly_mode
+        self.precond = precond           # 1 = multigrid-preconditioned CG (default), 0 = Jacobi-PCG
         self.problem = None
         self._key = None
 
@@ -120,9 +121,10 @@ class SimulationSession:
         tag_to_rc = {self.material_tags[m.name]: m.properties["rho_cv"] for m in stack.materials}
         return tag_to_k, tag_to_rc
 
-    def run(self, cfg, stack, watcher_points=None, field_sink=None):
+    def run(self, cfg, stack, watcher_points=None, field_sink=None, read_flux=False):
         """One simulation (reference loop run_with_diamond.py:456-504).  Returns a dict with
-        ``times``, ``watchers`` {name: array}, ``iters``, timing numbers."""
+        ``times``, ``watchers`` {name: array}, ``iters``, timing numbers.  ``read_flux`` adds the
+        per-step gradient projection of run_no_diamond.py:543-566 (``flux`` entry of the result)."""
         t_start = time.time()
         t_final = float(cfg["timing"]["t_final"])
         num_steps = int(cfg["timing"]["num_steps"])
@@ -145,7 +147,8 @@ class SimulationSession:
             print("Assigning material properties...")
             self.problem = HeatProblem(self.coords, self.tris, self.tags, tag_to_k, tag_to_rc, dt, bcs, ic_temp,
                                        backend=self.backend, device_id=self.device_id, rtol=self.rtol,
-                                       max_it=self.max_it, assembly_mode=self.assembly_mode)
+                                       max_it=self.max_it, assembly_mode=self.assembly_mode, precond=self.precond,
+                                       amg_reuse=True)
             self._key = key
             self._k = dict(tag_to_k)
             print("Material properties assigned.")
@@ -161,22 +164,32 @@ class SimulationSession:
         names, coords_w = _parse_watchers(watcher_points)
         nodes = nearest_nodes(self.coords, coords_w) if names else None
 
+        flux = FluxSampler(self.coords) if read_flux else None
+        if flux is not None:
+            print("Setting up radial heat flux sampling...")
+            prob.backend.flux_setup()
         print("Beginning loop...")
         t_loop = time.time()
-        if field_sink is None:
+        if field_sink is None and flux is None:
             times, samples, iters = prob.run(num_steps, watcher_nodes=nodes, time_varying=[bcs[3]])
-        else:  # step-wise so that every field can be handed to the sink (visualisation output)
+        else:  # step-wise: every field goes to the sink (visualisation) and / or through the flux projection
             for bc in bcs:
                 bc.update(0.0)
             times, rows, iters = [], [], []
             for step in range(num_steps):
                 t = (step + 1) * dt
                 it, _ = prob.step(t, only=[bcs[3]])
-                u = prob.state()
-                field_sink(t, u)
+                if flux is not None:
+                    _, grad_r = prob.backend.flux_project(self.rtol, 5000, want_z=False)
+                    flux.record(t, grad_r)
+                if field_sink is not None:
+                    u = prob.state()
+                    field_sink(t, u)
+                    rows.append(u[nodes] if nodes is not None else np.zeros(0))
+                else:
+                    rows.append(prob.backend.sample(nodes) if nodes is not None else np.zeros(0))
                 times.append(t)
                 iters.append(it)
-                rows.append(u[nodes] if nodes is not None else np.zeros(0))
             times, samples, iters = np.array(times), np.array(rows), np.array(iters)
         loop_time = time.time() - t_loop
         print(f"Simulation progress: 100% (step {num_steps}/{num_steps}) | Avg time/step: {loop_time / num_steps:.4f} s"
@@ -185,8 +198,55 @@ class SimulationSession:
             "times": np.asarray(times), "watcher_names": names,
             "watchers": {nm: samples[:, k] for k, nm in enumerate(names)},
             "iters": np.asarray(iters), "loop_time": loop_time, "startup_time": t_loop - t_start,
-            "n_dof": prob.n, "dt": dt,
+            "n_dof": prob.n, "dt": dt, "flux": flux,
         }
+
+
+class FluxSampler:
+    """Bookkeeping of run_no_diamond's radial-gradient outputs (reference run_no_diamond.py):
+    * smoothed: mean of d T/d r over the nodes with 0 < r <= 0.25 um that fall into each 0.2-um z bin
+      (:494-513, :553-556) -> ``radial_gradient.csv`` (columns = bin centres, :603-608);
+    * raw: d T/d r at the nodes on the axis (|r| <= 1e-12), ordered by z (:457-465, :559-566)
+      -> ``radial_gradient_raw.csv`` (columns = their z, :611-617)."""
+
+    DZ_BIN = 0.2e-6
+    BAND = 0.25e-6
+    R_TOL = 1e-12
+
+    def __init__(self, coords):
+        z, r = coords[:, 0], coords[:, 1]
+        edges = np.arange(z.min(), z.max() + self.DZ_BIN, self.DZ_BIN)
+        band = np.nonzero((r > 0.0) & (r <= self.BAND))[0]
+        k = np.searchsorted(edges, z[band]) - 1
+        ok = (k >= 0) & (k < len(edges) - 1)
+        band, k = band[ok], k[ok]
+        self.z_centres, self.groups = [], []
+        for b in np.unique(k):
+            self.z_centres.append(0.5 * (edges[b] + edges[b + 1]))
+            self.groups.append(band[k == b])
+        axis = np.nonzero(np.abs(r) <= self.R_TOL)[0]
+        order = np.argsort(z[axis], kind="stable")
+        self.axis_nodes = axis[order]
+        self.axis_z = z[self.axis_nodes]
+        self.times, self.rows, self.raw_rows = [], [], []
+
+    def record(self, t, grad_r):
+        self.times.append(float(t))
+        self.rows.append([float(np.mean(grad_r[g])) for g in self.groups])
+        self.raw_rows.append(grad_r[self.axis_nodes].astype(float).tolist())
+
+    @staticmethod
+    def _write(path, times, columns, rows):
+        with open(path, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["time"] + [repr(float(c)) for c in columns])
+            for t, row in zip(times, rows):
+                w.writerow([repr(t)] + [repr(v) for v in row])
+
+    def write(self, folder):
+        if self.rows:
+            self._write(os.path.join(folder, "radial_gradient.csv"), self.times, self.z_centres, self.rows)
+            self._write(os.path.join(folder, "radial_gradient_raw.csv"), self.times, self.axis_z, self.raw_rows)
 
 
 def write_watcher_csv(path, times, names, watchers):
@@ -222,7 +282,7 @@ class _FieldWriter:
 
 def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_mesh=False, output_folder=None,
                         watcher_points=None, write_xdmf=True, suppress_print=False, *, device_id=0, backend=None,
-                        session=None, rtol=DEFAULT_RTOL, max_it=DEFAULT_MAX_IT):
+                        session=None, rtol=DEFAULT_RTOL, max_it=DEFAULT_MAX_IT, read_flux=True, precond=None):
     with suppress_output(suppress_print):
         program_start = time.time()
         stack = stack_with_diamond(cfg) if kind == "with_diamond" else stack_no_diamond(cfg)
@@ -230,7 +290,7 @@ def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_me
         if own_session:
             coords, tris, tags, tag_map = prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack)
             session = SimulationSession(coords, tris, tags, tag_map, device_id=device_id, backend=backend, rtol=rtol,
-                                        max_it=max_it)
+                                        max_it=max_it, precond=1 if precond is None else precond)
         if visualize_mesh:
             print("visualize_mesh: the gmsh GUI is not part of this build; open mesh.msh in gmsh instead.")
         _parse_watchers(watcher_points)  # validate before any work, as the reference does at :431-439
@@ -248,7 +308,7 @@ def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_me
         try:
             if sink is not None:
                 sink(0.0, np.full(len(session.coords), float(cfg["heating"]["ic_temp"])))
-            result = session.run(cfg, stack, watcher_points, field_sink=sink)
+            result = session.run(cfg, stack, watcher_points, field_sink=sink, read_flux=read_flux and kind == "no_diamond")
         finally:
             if sink is not None:
                 sink.close()
@@ -258,6 +318,9 @@ def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_me
         if watcher_points is not None:
             write_watcher_csv(os.path.join(save_folder, "watcher_points.csv"), result["times"], result["watcher_names"],
                               result["watchers"])
+        if result.get("flux") is not None:
+            result["flux"].write(save_folder)
+            print(f"Saved raw gradient data at r=0 nodes to {os.path.join(save_folder, 'radial_gradient_raw.csv')}")
         total = time.time() - program_start
         n_steps = len(result["times"])
         print("\n--- Timing Summary ---")

@@ -22,7 +22,7 @@ K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS = range(6)
 EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_materials",
     "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_get_amg_info", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
-    "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
+    "hf_flux_setup", "hf_flux_project", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
 
 
@@ -90,6 +90,8 @@ def load_library():
         "hf_sample": [vp, i32, pi, pd],
         "hf_step": [vp, pd, dbl, dbl, i32, pi, pd],
         "hf_run": [vp, i32, pd, dbl, dbl, i32, i32, pi, pd, pi],
+        "hf_flux_setup": [vp],
+        "hf_flux_project": [vp, dbl, i32, pd, pd, pi],
         "hf_get_sizes": [vp, pi, pi, C.POINTER(i64), pi],
         "hf_get_csr": [vp, pi, pi, pd, pd],
         "hf_spmv": [vp, i32, pd, pd],
@@ -246,6 +248,19 @@ class HeatflowHIP:
         self.last_run_iters = iters
         self._check(rc)
         return samples, iters
+
+    # -- read-flux projection (run_no_diamond) ----------------------------------------------
+    def flux_setup(self):
+        self._check(self._lib.hf_flux_setup(self._ctx))
+
+    def flux_project(self, rtol=1e-10, max_it=5000, want_z=True, want_r=True):
+        """(grad_z, grad_r) of the current state, L2-projected onto P1 with weight r."""
+        gz = np.empty(self.n, dtype=np.float64) if want_z else None
+        gr = np.empty(self.n, dtype=np.float64) if want_r else None
+        it = np.zeros(2, dtype=np.int32)
+        self._check(self._lib.hf_flux_project(self._ctx, rtol, int(max_it), _pd(gz), _pd(gr), _pi(it)))
+        self.last_flux_iters = it
+        return gz, gr
 
     # -- inspection ----------------------------------------------------------------------
     def get_csr(self, values=True):

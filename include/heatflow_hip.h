@@ -17,6 +17,8 @@
  *                      set_bc; solver.solve(b, u_n)         run_with_diamond.py:474-481
  *   hf_sample          u_n.x.array[node_idx]                run_with_diamond.py:485-493
  *   hf_get_state       u_n.x.array (what xdmf.write_function would write)   :483-484
+ *   hf_flux_setup      assemble_matrix(a_proj) + KSP/LU set-up       run_no_diamond.py:471-491
+ *   hf_flux_project    assemble_vector(rhs_proj) + solver_proj.solve run_no_diamond.py:543-550
  *
  * Conventions
  *   - All functions return 0 (HF_OK) or a negative HF_ERR_* code; hf_last_error(ctx)
@@ -117,6 +119,15 @@ int hf_step(hf_ctx* ctx, const double* g_bc, double rtol, double atol, int32_t m
  * are sampled into samples (n_steps x n_s).  iters = n_steps entries (may be NULL). */
 int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_bc_all, double rtol, double atol, int32_t max_it,
            int32_t n_s, const int32_t* nodes, double* samples, int32_t* iters);
+
+/* Read-flux projection of run_no_diamond (reference run_no_diamond.py:471-491 set-up, :543-550 per
+ * step): grad_smooth = L2 projection of grad(T) onto vector P1 with weight r.  hf_flux_setup
+ * assembles the unit-coefficient r-weighted mass matrix on the mesh's pattern (once per mesh);
+ * hf_flux_project projects the CURRENT state: two Jacobi-PCG solves (z and r component, same
+ * stopping rule as hf_step), results copied to grad_z / grad_r (n values each, either may be
+ * NULL); iters = 2 entries (may be NULL). */
+int hf_flux_setup(hf_ctx* ctx);
+int hf_flux_project(hf_ctx* ctx, double rtol, int32_t max_it, double* grad_z, double* grad_r, int32_t* iters);
 
 int hf_get_sizes(hf_ctx* ctx, int32_t* n, int32_t* n_e, int64_t* nnz, int32_t* n_bc);
 /* Any pointer may be NULL.  A is the matrix as it stands (eliminated when BCs are set). */

@@ -377,6 +377,40 @@ def run_reference_algorithm(cfg, coords, tris, tags, material_tags, heating_csv,
 
 
 # --------------------------------------------------------------------------------------
+# Read-flux projection (run_no_diamond.py:471-491 set-up, :543-550 per step)
+#   a_proj = inner(g, w) r dx on vector P1, rhs = inner(grad(u_n), w) r dx  ->  grad_smooth
+# The 2n x 2n block system is block-diagonal in the two components: each is M_r(1) g_c = b_c.
+# --------------------------------------------------------------------------------------
+
+
+class GradientProjector:
+    def __init__(self, coords, tris):
+        self.coords = np.asarray(coords, dtype=np.float64)
+        self.tris = np.asarray(tris, dtype=np.int64)
+        ne = len(self.tris)
+        Me, _ = element_matrices(self.coords, self.tris, np.ones(ne), np.zeros(ne))
+        self.M1 = assemble_csr(len(self.coords), self.tris, Me)
+        self._lu = spla.splu(self.M1.tocsc())
+        p = self.coords[self.tris]
+        z, r = p[:, :, 0], p[:, :, 1]
+        self.d = (z[:, 1] - z[:, 0]) * (r[:, 2] - r[:, 0]) - (z[:, 2] - z[:, 0]) * (r[:, 1] - r[:, 0])
+        self.bz = np.stack([r[:, 1] - r[:, 2], r[:, 2] - r[:, 0], r[:, 0] - r[:, 1]], axis=1) / self.d[:, None]
+        self.br = np.stack([z[:, 2] - z[:, 1], z[:, 0] - z[:, 2], z[:, 1] - z[:, 0]], axis=1) / self.d[:, None]
+        area = 0.5 * np.abs(self.d)
+        self.w = area[:, None] * (r + r.sum(axis=1)[:, None]) / 12.0      # int_e phi_i r dx
+
+    def project(self, u):
+        """(n, 2) array [dT/dz, dT/dr] = grad_smooth.x.array.reshape(-1, 2) (run_no_diamond.py:553)."""
+        ue = np.asarray(u)[self.tris]
+        gz = (ue * self.bz).sum(axis=1)
+        gr = (ue * self.br).sum(axis=1)
+        n = len(self.coords)
+        rhs_z = np.bincount(self.tris.ravel(), weights=(gz[:, None] * self.w).ravel(), minlength=n)
+        rhs_r = np.bincount(self.tris.ravel(), weights=(gr[:, None] * self.w).ravel(), minlength=n)
+        return np.column_stack([self._lu.solve(rhs_z), self._lu.solve(rhs_r)])
+
+
+# --------------------------------------------------------------------------------------
 # 1-D P1 interval model (run_no_diamond_1d.py:537-546): no r weight
 # --------------------------------------------------------------------------------------
 

@@ -76,5 +76,12 @@ class OracleBackend:
                 samples[k] = self.u[np.asarray(nodes)]
         return samples, np.ones(len(g_all), dtype=np.int32)
 
+    def flux_setup(self):
+        self._proj = ho.GradientProjector(self.coords, self.tris)
+
+    def flux_project(self, rtol=1e-10, max_it=5000, want_z=True, want_r=True):
+        g = self._proj.project(self.u)
+        return (g[:, 0].copy() if want_z else None), (g[:, 1].copy() if want_r else None)
+
     def last_gpu_ms(self):
         return 0.0

@@ -39,6 +39,18 @@ def test_run_simulation_outputs_and_mesh_cache(tmp_path, module, name):
     res = run.run_simulation(cfg, mesh_folder, rebuild_mesh=True, output_folder=out, watcher_points=wp,
                              write_xdmf=False, suppress_print=True, backend=OracleBackend())
     assert sorted(os.listdir(mesh_folder)) == ["mesh.msh", "mesh.npz", "mesh_cfg.yaml"]
+    has_flux = os.path.isfile(os.path.join(out, "radial_gradient.csv"))
+    assert has_flux == (module == "run_no_diamond")                  # read-flux CSVs only from run_no_diamond
+    if has_flux:
+        with open(os.path.join(out, "radial_gradient.csv")) as f:
+            g = list(csv.reader(f))
+        with open(os.path.join(out, "radial_gradient_raw.csv")) as f:
+            graw = list(csv.reader(f))
+        assert g[0][0] == "time" and len(g) == 9 and len(graw) == 9
+        zc = np.array(g[0][1:], dtype=float)
+        assert np.all(np.diff(zc) > 0) and np.allclose(np.diff(zc) / 0.2e-6, np.round(np.diff(zc) / 0.2e-6))
+        zr = np.array(graw[0][1:], dtype=float)
+        assert np.all(np.diff(zr) > 0) and zr[0] == pytest.approx(-4.182e-6)
     with open(os.path.join(mesh_folder, "mesh_cfg.yaml")) as f:
         mcfg = yaml.safe_load(f)
     assert mcfg["material_tags"]["p_ins"] >= 1 and "mats" in mcfg

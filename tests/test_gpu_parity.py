@@ -238,3 +238,84 @@ def test_amg_cuts_iterations_and_frozen_hierarchy_survives_a_kappa_change(hip, c
     finally:
         pj.close()
         pa.close()
+
+
+def test_read_flux_projection_matches_oracle(hip, case_no_diamond_small):
+    """run_no_diamond's per-step L2 projection of grad T (r-weighted vector-P1 mass system)."""
+    from oracle import heat_oracle as ho
+
+    cfg, stack, mesh = case_no_diamond_small
+    ref = oracle_run(cfg, mesh, 8)
+    proj = ho.GradientProjector(mesh.coords, mesh.tris)
+    prob = make_problem(cfg, stack, mesh)
+    try:
+        prob.backend.flux_setup()
+        for bc in prob.bcs:
+            bc.update(0.0)
+        for k in range(8):
+            prob.step((k + 1) * prob.dt)
+            g_ref = proj.project(ref["fields"][k])
+            scale = max(np.abs(g_ref).max(), 1.0)                     # K/m (the field is still flat at step 0)
+            # end to end: the 1e-6 K solver difference is amplified by 1/h ~ 1e8 /m
+            gz, gr = prob.backend.flux_project(rtol=1e-12)
+            assert np.abs(gr - g_ref[:, 1]).max() <= 1e-4 * scale + 1e-3
+            # the projection itself, on identical input
+            prob.set_state(ref["fields"][k])
+            gz, gr = prob.backend.flux_project(rtol=1e-12)
+            # 1e-3 K/m absolute: roundoff of a 300 K field (1e-13 K) over h ~ 1e-8 m is ~1e-5 K/m
+            assert np.abs(gz - g_ref[:, 0]).max() <= 1e-8 * scale + 1e-3
+            assert np.abs(gr - g_ref[:, 1]).max() <= 1e-8 * scale + 1e-3
+        assert scale > 1e6                                            # steep gradients near the heated line
+        assert prob.backend.last_flux_iters.max() < 200
+    finally:
+        prob.close()
+
+
+@pytest.mark.parametrize("module,name", [("run_with_diamond", "geballe_with_diamond"), ("run_no_diamond", "geballe_no_diamond")])
+def test_entry_points_end_to_end_on_gpu(hip, tmp_path, module, name):
+    """The reference-named entry points on the real backend: watcher CSV (and, for run_no_diamond,
+    the read-flux CSVs) against the oracle run on the mesh the driver cached."""
+    import csv
+    import importlib
+    import os
+
+    from conftest import load_cfg
+    from heatflow_amd.geometry import scale_mesh_sizes, watcher_points
+    from heatflow_amd.mesh import load_mesh_arrays
+    from heatflow_amd.solver import nearest_nodes
+    from oracle import heat_oracle as ho
+    import yaml
+
+    run = importlib.import_module(module)
+    cfg = scale_mesh_sizes(load_cfg(name), 8.0)
+    cfg["timing"]["num_steps"] = 12
+    cfg["timing"]["t_final"] = 12 * (7.5e-8 if "with" in name else 1.875e-7)
+    mesh_folder, out = str(tmp_path / "mesh"), str(tmp_path / "out")
+    wp = watcher_points(cfg)
+    res = run.run_simulation(cfg, mesh_folder, rebuild_mesh=True, output_folder=out, watcher_points=wp,
+                             write_xdmf=False, suppress_print=True)
+    coords, tris, tags = load_mesh_arrays(os.path.join(mesh_folder, "mesh.msh"))
+    with open(os.path.join(mesh_folder, "mesh_cfg.yaml")) as f:
+        mtags = yaml.safe_load(f)["material_tags"]
+    nodes = nearest_nodes(coords, list(wp.values()))
+    from conftest import HEATING_CSV
+    ref = ho.run_reference_algorithm(cfg, coords, tris, tags, mtags, HEATING_CSV, keep_fields=True, watcher_nodes=nodes)
+    with open(os.path.join(out, "watcher_points.csv")) as f:
+        rows = list(csv.reader(f))
+    got = np.array(rows[1:], dtype=float)
+    assert rows[0] == ["time", "pside", "oside"]
+    assert np.allclose(got[:, 0], ref["times"], rtol=0, atol=1e-20)
+    assert np.abs(got[:, 1:] - ref["watchers"]).max() <= FIELD_TOL_K
+    assert res["iters"].max() < 40                                     # multigrid-preconditioned by default
+    if module == "run_no_diamond":
+        proj = ho.GradientProjector(coords, tris)
+        with open(os.path.join(out, "radial_gradient_raw.csv")) as f:
+            raw = list(csv.reader(f))
+        zcol = np.array(raw[0][1:], dtype=float)
+        axis = np.nonzero(np.abs(coords[:, 1]) <= 1e-12)[0]
+        axis = axis[np.argsort(coords[axis, 0], kind="stable")]
+        assert np.array_equal(zcol, coords[axis, 0])
+        g_last = proj.project(ref["fields"][-1])[axis, 1]
+        got_last = np.array(raw[-1][1:], dtype=float)
+        assert np.abs(got_last - g_last).max() <= 1e-4 * max(np.abs(g_last).max(), 1.0) + 1e-3
+        assert os.path.isfile(os.path.join(out, "radial_gradient.csv"))
