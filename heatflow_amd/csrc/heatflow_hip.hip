@@ -11,6 +11,7 @@
 // (assemble once, symmetric Dirichlet elimination, solve), :469-481 (loop body).
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -946,10 +947,20 @@ int launch_assemble(hf_ctx* ctx) {
 template <int MODE>
 void launch_spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr,
                  const double* bvec = nullptr, double* pvec = nullptr, double* part1 = nullptr,
-                 double* part2 = nullptr, double w = 0.0, const double* dinv = nullptr) {
-  hipLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), spmv_smem_bytes(c), c->stream, c->n, c->nchunks_s, TS,
-                     c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, dinv ? dinv : c->d_dinv, pvec, part1,
-                     part2, w, c->P);
+                 double* part2 = nullptr, double w = 0.0, const double* dinv = nullptr, hipEvent_t ev_start = nullptr,
+                 hipEvent_t ev_stop = nullptr) {
+  // With events: the launch carries them (hipExtLaunchKernelGGL), so they bracket the kernel's own
+  // execution on the device - the same interval rocprofv3 reports - not the launch gap before it.
+  if (ev_start != nullptr)
+    hipExtLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), static_cast<std::uint32_t>(spmv_smem_bytes(c)), c->stream,
+                          ev_start, ev_stop, 0u, c->n, c->nchunks_s, static_cast<int>(TS),
+                          static_cast<const int32_t*>(c->d_rowptr), static_cast<const int32_t*>(c->d_colidx), vals, x, y,
+                          static_cast<const Scal*>(c->d_scal), part0, bvec, dinv ? dinv : static_cast<const double*>(c->d_dinv),
+                          pvec, part1, part2, w, c->P);
+  else
+    hipLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), spmv_smem_bytes(c), c->stream, c->n, c->nchunks_s, TS,
+                       c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, dinv ? dinv : c->d_dinv, pvec, part1,
+                       part2, w, c->P);
 }
 
 constexpr int PROF_PAIRS = 64;
@@ -959,9 +970,13 @@ struct LinSys { const double* A; const double* dinv; double* x; const double* b;
 
 void launch_pcg_iteration(hf_ctx* c, const LinSys& s, int parity) {
   const bool timed = c->prof && c->prof_used < PROF_PAIRS;
-  if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_used], c->stream);
-  launch_spmv<1>(c, s.A, c->d_p, c->d_Ap, c->d_part_pAp);
-  if (timed) { (void)hipEventRecord(c->prof_ev[2 * c->prof_used + 1], c->stream); c->prof_used++; }
+  if (timed) {
+    launch_spmv<1>(c, s.A, c->d_p, c->d_Ap, c->d_part_pAp, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr,
+                   c->prof_ev[2 * c->prof_used], c->prof_ev[2 * c->prof_used + 1]);
+    c->prof_used++;
+  } else {
+    launch_spmv<1>(c, s.A, c->d_p, c->d_Ap, c->d_part_pAp);
+  }
   hipLaunchKernelGGL(k_pcg_update, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
                      c->d_part_pAp, c->d_part_rz, c->d_part_zz, s.x, c->d_r, c->d_p, c->d_Ap, s.dinv);
   hipLaunchKernelGGL(k_pcg_dir, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
@@ -1150,9 +1165,13 @@ void vcycle(hf_ctx* c, int out_slot) {
 
 void launch_amg_iteration(hf_ctx* c, int parity) {
   const bool timed = c->prof && c->prof_used < PROF_PAIRS;
-  if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_used], c->stream);
-  launch_spmv<1>(c, c->d_A, c->d_p, c->d_Ap, c->d_part_pAp);
-  if (timed) { (void)hipEventRecord(c->prof_ev[2 * c->prof_used + 1], c->stream); c->prof_used++; }
+  if (timed) {
+    launch_spmv<1>(c, c->d_A, c->d_p, c->d_Ap, c->d_part_pAp, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr,
+                   c->prof_ev[2 * c->prof_used], c->prof_ev[2 * c->prof_used + 1]);
+    c->prof_used++;
+  } else {
+    launch_spmv<1>(c, c->d_A, c->d_p, c->d_Ap, c->d_part_pAp);
+  }
   hipLaunchKernelGGL(k_pcg_update_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
                      c->d_part_pAp, c->d_part_rz, c->d_part_zz, c->d_u, c->d_r, c->d_p, c->d_Ap, c->d_dinv,
                      c->amg[0].omega, c->d_z);

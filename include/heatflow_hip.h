@@ -139,8 +139,9 @@ int hf_spmv(hf_ctx* ctx, int32_t which, const double* x, double* y);
  * bracketed by HIP events on that stream. */
 int hf_time_kernel(hf_ctx* ctx, int32_t which, int32_t reps, double* ms_avg);
 /* In-situ timing of the dominant kernel: while on, up to 64 PCG SpMV launches per host check
- * are bracketed by HIP event pairs on the ctx stream (launches skipped after convergence are
- * not counted).  hf_get_profile returns the summed duration and the number of launches. */
+ * carry a HIP event pair on the ctx stream (hipExtLaunchKernelGGL start/stop events: the
+ * kernel's own execution interval; launches skipped after convergence are not counted).
+ * hf_get_profile returns the summed duration and the number of launches. */
 int hf_set_profile(hf_ctx* ctx, int32_t on);
 int hf_get_profile(hf_ctx* ctx, double* spmv_ms_sum, int64_t* spmv_launches);
 /* GPU time (ms, HIP events on the ctx stream) of the last hf_step / hf_run / hf_assemble. */

@@ -1,0 +1,40 @@
+"""Summarise two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM bytes per launch.
+
+    python scripts/pmc_summary.py <fetch_dir> <write_dir> <out_prefix> <n> <n_e> <nnz>
+
+bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts 64 B per 128-B request
+(MI355X_MICROARCH.md, HBM); the factor is calibrated here on the vector kernels, whose byte
+count is known exactly (k_pcg_update reads 40 B/row)."""
+import collections, csv, glob, json, re, statistics, sys
+
+fetch_dir, write_dir, out, n, ne, nnz = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+
+
+def short(name):
+    m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:30]
+
+
+res = {}
+for kind, d in (("fetch", fetch_dir), ("write", write_dir)):
+    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    res[kind] = acc
+alg = {"k_spmv<1>": 12 * nnz + 20 * n, "k_spmv<0>": 12 * nnz + 20 * n, "k_spmv<3>": 12 * nnz + 28 * n,
+       "k_spmv<4>": 12 * nnz + 36 * n, "k_pcg_update_amg": 64 * n, "k_pcg_update": 56 * n, "k_pcg_dir": 32 * n,
+       "k_pcg_dir_amg": 24 * n, "k_assemble_lds<false>": 16 * ne + 16 * n + 16 * nnz}
+kern = {}
+with open(out + ".csv", "w") as f:
+    f.write("kernel,launches,FETCH_SIZE_KB_p90,WRITE_SIZE_KB_p90,hbm_bytes_per_launch_corrected,algorithmic_bytes,ratio\n")
+    for k in sorted(res["fetch"], key=lambda k: -sum(res["fetch"][k])):
+        fv, wv = sorted(res["fetch"][k]), sorted(res["write"].get(k, [0.0]))
+        fk, wk = fv[max(0, int(0.9 * len(fv)) - 1)], wv[max(0, int(0.9 * len(wv)) - 1)]   # p90: skips no-op launches
+        corr = (2 * fk + wk) * 1024
+        a = alg.get(k)
+        f.write(f"{k},{len(fv)},{fk:.0f},{wk:.0f},{corr:.0f},{a if a else ''},{(corr / a if a else float('nan')):.3f}\n")
+        if a:
+            kern[k] = {"hbm_bytes": corr, "algorithmic": a}
+json.dump({"n": n, "nnz": nnz, "note": __doc__.split("bytes =")[1].strip(), "kernels": kern}, open(out + ".json", "w"), indent=1)
+print(open(out + ".csv").read())
