@@ -89,6 +89,9 @@ struct hf_ctx {
   double* d_lift_val = nullptr;
   // device: vectors
   double *d_u = nullptr, *d_b = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr;
+  double *d_uprev = nullptr, *d_ustart = nullptr;   // u^{n-1} and the buffer of the next start vector (rotated with d_u)
+  bool have_prev = false;
+  int extrapolate = 1;         // start PCG from 2 u^n - u^{n-1} (same answer, fewer iterations)
   double *d_tmp = nullptr;
   // device: reductions
   double *d_part_pAp = nullptr, *d_part_rz = nullptr, *d_part_zz = nullptr, *d_part_bn = nullptr;
@@ -474,6 +477,8 @@ __global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* 
 //   MODE 6: y += A x                                                 (multigrid prolongation)
 //   MODE 7: p = w D^-1 b; y = b - A p   (first Jacobi sweep from zero fused with the residual;
 //           the products gather w*dinv[col]*b[col], so p is never read back)
+//   MODE 8: y = A x; p = 2 x - b        (RHS b = M u^n fused with the extrapolated start
+//           2 u^n - u^{n-1} of the next solve; `b` carries u^{n-1})
 // The chunk is `rpc` rows (512 for the fine operator; fewer for long-row transfer operators so
 // that a chunk's products fit the 64-KB LDS window).
 // ------------------------------------------------------------------------------------------
@@ -550,10 +555,13 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
         acc2 += (di * bi) * (di * bi);
       } else if (MODE == 6) {
         y[row] += s;
-      } else {
+      } else if (MODE == 7) {
         const double bi = bvec[row];
         pvec[row] = w * dinv[row] * bi;
         y[row] = bi - s;
+      } else {
+        y[row] = s;
+        pvec[row] = 2.0 * x[row] - bvec[row];
       }
     }
     __syncthreads();
@@ -1252,8 +1260,21 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
 // One time step with g already in d_g.  Leaves iteration count / residual in h_scal.
 int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
   const int nb = ctx->nbc;
-  // b = M u^n   (assemble_vector, run_with_diamond.py:476)
-  launch_spmv<0>(ctx, ctx->d_M, ctx->d_u, ctx->d_b);
+  // b = M u^n   (assemble_vector, run_with_diamond.py:476); with a previous step available the same
+  // pass writes the extrapolated start vector 2 u^n - u^{n-1}, and the three state buffers rotate
+  if (ctx->extrapolate && ctx->have_prev) {
+    launch_spmv<8>(ctx, ctx->d_M, ctx->d_u, ctx->d_b, nullptr, ctx->d_uprev, ctx->d_ustart);
+    double* old_prev = ctx->d_uprev;
+    ctx->d_uprev = ctx->d_u;        // u^n
+    ctx->d_u = ctx->d_ustart;       // iterate, becomes u^{n+1}
+    ctx->d_ustart = old_prev;
+  } else {
+    launch_spmv<0>(ctx, ctx->d_M, ctx->d_u, ctx->d_b);
+    if (ctx->extrapolate) {         // keep u^n for the next step
+      HF_HIP(hipMemcpyAsync(ctx->d_uprev, ctx->d_u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+      ctx->have_prev = true;
+    }
+  }
   if (nb > 0) {
     if (ctx->nlift_rows > 0)  // apply_lifting (:477)
       hipLaunchKernelGGL(k_lift, dim3((ctx->nlift_rows + 255) / 256), dim3(256), 0, ctx->stream, ctx->nlift_rows,
@@ -1361,6 +1382,7 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent); dev_free(&ctx->d_blk_el); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
   dev_free(&ctx->d_bc_dofs); dev_free(&ctx->d_g); dev_free(&ctx->d_lift_rows); dev_free(&ctx->d_lift_ptr);
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
+  dev_free(&ctx->d_uprev); dev_free(&ctx->d_ustart);
   dev_free(&ctx->d_u); dev_free(&ctx->d_b); dev_free(&ctx->d_r); dev_free(&ctx->d_p); dev_free(&ctx->d_Ap);
   free_amg(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
   dev_free(&ctx->d_M1); dev_free(&ctx->d_dinv1); dev_free(&ctx->d_gz); dev_free(&ctx->d_gr); dev_free(&ctx->d_bz); dev_free(&ctx->d_br);
@@ -1425,6 +1447,9 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_TRY(dev_alloc(ctx, &ctx->d_A, ctx->nnz));
   HF_TRY(dev_alloc(ctx, &ctx->d_dinv, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_u, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_uprev, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_ustart, n));
+  ctx->have_prev = false;
   HF_TRY(dev_alloc(ctx, &ctx->d_b, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_r, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_p, n));
@@ -1526,6 +1551,7 @@ int hf_assemble(hf_ctx* ctx, double dt, int32_t mode) {
   }
   ctx->assembled = true;
   ctx->pred_iters = 0;
+  ctx->have_prev = false;
   return HF_OK;
 }
 
@@ -1617,6 +1643,7 @@ int hf_set_state(hf_ctx* ctx, const double* u) {
   HF_HIP(hipSetDevice(ctx->dev));
   HF_HIP(hipMemcpyAsync(ctx->d_u, u, sizeof(double) * ctx->n, hipMemcpyHostToDevice, ctx->stream));
   HF_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->have_prev = false;
   return HF_OK;
 }
 

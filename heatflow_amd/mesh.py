@@ -397,14 +397,27 @@ def write_msh(filename, coords, tris, tags, names=None):
 
 
 def read_msh(filename):
-    """Read the MSH 2.2 ASCII subset written by :func:`write_msh` (also what gmsh writes
-    with ``Mesh.MshFileVersion = 2.2``): returns (coords (n,2), tris (ne,3) int32, tags)."""
+    """Read a Gmsh ASCII mesh: MSH 2.2 (what :func:`write_msh` writes) or MSH 4.1 (what the
+    reference's ``gmsh.write`` produces by default).  Returns (coords (n,2), tris (ne,3) int32,
+    tags (ne,) int32).  The cell tag is the triangle's *physical group* (the tag
+    ``gmshio.model_to_mesh`` hands to dolfinx, run_with_diamond.py:244), falling back to the
+    surface id when a surface has no physical group.  Points / lines are skipped."""
     with open(filename) as f:
         lines = f.read().split("\n")
     pos = {ln.strip(): k for k, ln in enumerate(lines) if ln.startswith("$")}
+    if "$MeshFormat" not in pos:
+        raise MeshError(f"{filename}: not a Gmsh mesh file")
     fmt = lines[pos["$MeshFormat"] + 1].split()
-    if not fmt or not fmt[0].startswith("2"):
-        raise MeshError(f"{filename}: only MSH 2.x ASCII is supported (found {fmt[:1]})")
+    if len(fmt) >= 2 and fmt[1] != "0":
+        raise MeshError(f"{filename}: binary MSH files are not supported, export ASCII")
+    if fmt and fmt[0].startswith("2"):
+        return _read_msh2(lines, pos)
+    if fmt and fmt[0].startswith("4.1"):
+        return _read_msh41(lines, pos)
+    raise MeshError(f"{filename}: unsupported MSH version {fmt[:1]} (2.2 and 4.1 ASCII are read)")
+
+
+def _read_msh2(lines, pos):
     k = pos["$Nodes"]
     n = int(lines[k + 1])
     nodes = np.loadtxt(lines[k + 2:k + 2 + n], ndmin=2)
@@ -423,6 +436,58 @@ def read_msh(filename):
         tris.append([int(v) for v in p[3 + ntag:3 + ntag + 3]])
     tris = remap[np.array(tris, dtype=np.int64)].astype(np.int32)
     return nodes[:, 1:3].copy(), tris, np.array(tags, dtype=np.int32)
+
+
+def _read_msh41(lines, pos):
+    # surface entity -> physical tag
+    surf_phys = {}
+    if "$Entities" in pos:
+        k = pos["$Entities"] + 1
+        npnt, ncur, nsur, _nvol = (int(v) for v in lines[k].split())
+        k += 1 + npnt + ncur
+        for ln in lines[k:k + nsur]:
+            p = ln.split()
+            nphys = int(p[7])
+            if nphys:
+                surf_phys[int(p[0])] = abs(int(p[8]))
+    k = pos["$Nodes"] + 1
+    nblocks, nnodes = (int(v) for v in lines[k].split()[:2])
+    k += 1
+    ids = np.empty(nnodes, dtype=np.int64)
+    xyz = np.empty((nnodes, 3), dtype=np.float64)
+    at = 0
+    for _ in range(nblocks):
+        _dim, _tag, parametric, nb = (int(v) for v in lines[k].split())
+        k += 1
+        ids[at:at + nb] = [int(v) for v in lines[k:k + nb]]
+        k += nb
+        for q in range(nb):
+            xyz[at + q] = [float(v) for v in lines[k + q].split()[:3]]
+        k += nb
+        at += nb
+    remap = np.full(ids.max() + 1, -1, dtype=np.int64)
+    remap[ids] = np.arange(nnodes)
+    k = pos["$Elements"] + 1
+    nblocks = int(lines[k].split()[0])
+    k += 1
+    tris, tags = [], []
+    for _ in range(nblocks):
+        dim, etag, etype, nb = (int(v) for v in lines[k].split())
+        k += 1
+        if dim == 2 and etype == 2:
+            tag = surf_phys.get(etag, etag)
+            for ln in lines[k:k + nb]:
+                p = ln.split()
+                tris.append([int(p[1]), int(p[2]), int(p[3])])
+                tags.append(tag)
+        k += nb
+    if not tris:
+        raise MeshError("no 3-node triangles in the MSH 4.1 file")
+    tris = remap[np.array(tris, dtype=np.int64)]
+    used = np.unique(tris)                       # gmsh may store nodes that only points/curves use
+    compact = np.full(nnodes, -1, dtype=np.int64)
+    compact[used] = np.arange(len(used))
+    return xyz[used, :2].copy(), compact[tris].astype(np.int32), np.array(tags, dtype=np.int32)
 
 
 def load_mesh_arrays(mesh_file_path):

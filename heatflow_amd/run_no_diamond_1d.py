@@ -10,9 +10,14 @@ and heating_offset(t) at z = mesh_zmin + z_ins_pside (:563-591, no Gaussian in 1
 once, loop (:712-790), outputs ``used_config.yaml`` / ``watcher_points.csv`` in
 ``sim_outputs/1d_simulation`` by default.
 
-The radial-loss source term (``use_radial_correction``, :316-378, :718-747) is SURVEY section 8
-item f3 and not built yet: asking for it raises NotImplementedError instead of silently running
-without it; pass ``use_radial_correction=False`` (the BASELINE C1 setting).
+The radial-loss source term (``use_radial_correction``) follows
+:316-378 (CSV discovery, bilinear (t, z) interpolation of dT/dr with clamping), :469-480 (delta_r =
+0.1 um for ``radial_gradient.csv``, 0.07 um for the raw file), :676-700 (kappa per node) and
+:718-747 (per-step source 2 kappa (dT/dr)/delta_r, x0.1 on nodes whose z was clamped), entering
+the right-hand side as dt * int s v dx (:546).  One reference quirk is kept selectable: it looks
+kappa up as ``kappa_per_cell[cell_tags_1d.values[cell_idx]]`` (:692), i.e. it indexes the
+per-cell array by a *tag value*; ``kappa_lookup="reference"`` (default, for identical numbers)
+does the same, ``kappa_lookup="cell"`` uses the conductivity of the node's own cell.
 """
 from __future__ import annotations
 
@@ -83,7 +88,7 @@ def _thomas_solve(fac, b):
 
 def run_1d(cfg, mesh_folder_2d, mesh_folder_1d=None, rebuild_mesh=False, visualize_mesh=False, output_folder=None,
            watcher_points=None, write_xdmf=True, suppress_print=False, use_radial_correction=True,
-           radial_gradient_path=None):
+           radial_gradient_path=None, *, kappa_lookup="reference"):
     with suppress_output(suppress_print):
         t_start = time.time()
         mesh_cfg_path = os.path.join(mesh_folder_2d, "mesh_cfg.yaml")
@@ -91,10 +96,7 @@ def run_1d(cfg, mesh_folder_2d, mesh_folder_1d=None, rebuild_mesh=False, visuali
         missing = [nm for nm, p in (("mesh.msh", mesh_file_path), ("mesh_cfg.yaml", mesh_cfg_path)) if not os.path.isfile(p)]
         if missing:
             raise FileNotFoundError(f"Missing required file(s) in {mesh_folder_2d}: {', '.join(missing)}")
-        if use_radial_correction:
-            raise NotImplementedError("radial heating correction (SURVEY 8 f3) is not built yet; "
-                                      "call run_1d(..., use_radial_correction=False)")
-        print("Radial heating correction: DISABLED (user choice)")
+        print("Radial heating correction: %s (user choice)" % ("ENABLED" if use_radial_correction else "DISABLED"))
         with open(mesh_cfg_path) as f:
             mat_tag_map = yaml.safe_load(f).get("material_tags", {})
         coords, tris, tags = load_mesh_arrays(mesh_file_path)
@@ -154,6 +156,50 @@ def run_1d(cfg, mesh_folder_2d, mesh_folder_1d=None, rebuild_mesh=False, visuali
             save_folder = os.path.join(os.getcwd(), "sim_outputs", "1d_simulation")
             os.makedirs(save_folder, exist_ok=True)
 
+        # ---- radial heating correction from a 2-D run's gradient CSV (reference :316-378)
+        grad = None
+        if use_radial_correction:
+            grad_file = radial_gradient_path
+            if grad_file is None:
+                bases = [os.path.join(mesh_folder_2d, "..", "outputs", "geballe_no_diamond_read_flux"),
+                         os.path.join(mesh_folder_2d, "..", "..", "outputs", "geballe_no_diamond_read_flux"),
+                         os.path.join(os.getcwd(), "outputs", "geballe_no_diamond_read_flux"),
+                         os.path.join(os.getcwd(), "sim_outputs", "geballe_no_diamond_read_flux")]
+                for fname in ("radial_gradient.csv", "radial_gradient_raw.csv"):
+                    hits = [os.path.join(b, fname) for b in bases if os.path.exists(os.path.join(b, fname))]
+                    if hits:
+                        grad_file = hits[0]
+                        break
+            if grad_file is None:
+                print("No radial gradient CSV found: radial correction switched off")   # as the reference does
+                use_radial_correction = False
+            else:
+                from scipy.interpolate import RegularGridInterpolator
+
+                with open(grad_file) as f:
+                    header = f.readline().strip().split(",")
+                table = np.loadtxt(grad_file, delimiter=",", skiprows=1, ndmin=2)
+                g_times, g_z, g_vals = table[:, 0], np.array(header[1:], dtype=float), table[:, 1:]
+                interp = RegularGridInterpolator((g_times, g_z), g_vals, method="linear")
+                delta_r = 0.1e-6 if "radial_gradient.csv" in grad_file else 0.07e-6
+                # node -> first cell (in cell order) whose span contains it (:676-686)
+                node_cell = np.maximum(np.arange(n) - 1, 0)
+                if kappa_lookup == "reference":
+                    idx = np.minimum(cell_tags[node_cell], len(kappa) - 1)      # tag value used as a cell index (:692)
+                    node_kappa = kappa[idx]
+                elif kappa_lookup == "cell":
+                    node_kappa = kappa[node_cell]
+                else:
+                    raise ValueError("kappa_lookup must be 'reference' or 'cell'")
+                z_cl = np.clip(z, g_z.min(), g_z.max())
+                clamped = z != z_cl
+                grad = (interp, g_times.min(), g_times.max(), z_cl, clamped, node_kappa, delta_r)
+                # un-weighted unit mass matrix for dt * int s v dx
+                s_off = h / 6.0
+                s_diag = np.zeros(n)
+                s_diag[:-1] += h / 3.0
+                s_diag[1:] += h / 3.0
+
         wnames, wcoords = _parse_watchers(watcher_points)
         wnodes = [int(np.argmin(np.abs(z - c[0]))) for c in wcoords]
 
@@ -169,6 +215,14 @@ def run_1d(cfg, mesh_folder_2d, mesh_folder_1d=None, rebuild_mesh=False, visuali
             b = m_diag * u
             b[:-1] += m_off * u[1:]
             b[1:] += m_off * u[:-1]
+            if grad is not None:
+                interp, t_lo, t_hi, z_cl, clamped, node_kappa, delta_r = grad
+                gv = interp(np.column_stack([np.full(n, np.clip(t, t_lo, t_hi)), z_cl]))
+                gv[clamped] *= 0.1
+                src = 2.0 * node_kappa * gv / delta_r
+                b += dt * s_diag * src
+                b[:-1] += dt * s_off * src[1:]
+                b[1:] += dt * s_off * src[:-1]
             # lifting with the unconstrained operator, then set_bc
             gfull = np.zeros(n)
             gfull[bc_dofs] = g

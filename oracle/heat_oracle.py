@@ -415,10 +415,11 @@ class GradientProjector:
 # --------------------------------------------------------------------------------------
 
 
-def solve_1d_slab(z, rho_c_cells, kappa_cells, dt, u0, bc_nodes, bc_value_fn, num_steps):
-    """Backward Euler for rho_c u_t = (kappa u_z)_z on nodes ``z`` (sorted) with P1
+def solve_1d_slab(z, rho_c_cells, kappa_cells, dt, u0, bc_nodes, bc_value_fn, num_steps, source_fn=None):
+    """Backward Euler for rho_c u_t = (kappa u_z)_z + s on nodes ``z`` (sorted) with P1
     intervals, Dirichlet nodes ``bc_nodes`` (values ``bc_value_fn(t)`` -> array),
-    consistent mass matrix - the un-weighted forms of run_no_diamond_1d.py:537-546.
+    consistent mass matrix - the un-weighted forms of run_no_diamond_1d.py:537-546;
+    ``source_fn(t)`` -> nodal values of the P1 source (dt * int s v dx, :546).
     Returns (num_steps, n) array."""
     n = len(z)
     h = np.diff(z)
@@ -432,6 +433,10 @@ def solve_1d_slab(z, rho_c_cells, kappa_cells, dt, u0, bc_nodes, bc_value_fn, nu
     main_k[1:] += kappa_cells / h
     M = sp.diags([off_m, main_m, off_m], [-1, 0, 1]).tocsr()
     A = (M + dt * sp.diags([off_k, main_k, off_k], [-1, 0, 1])).tocsr()
+    main_1 = np.zeros(n)
+    main_1[:-1] += h / 3.0
+    main_1[1:] += h / 3.0
+    M1 = sp.diags([h / 6.0, main_1, h / 6.0], [-1, 0, 1]).tocsr()
     bc_nodes = np.asarray(bc_nodes)
     Ah = eliminate_dirichlet(A, bc_nodes)
     lu = spla.splu(Ah.tocsc())
@@ -441,6 +446,8 @@ def solve_1d_slab(z, rho_c_cells, kappa_cells, dt, u0, bc_nodes, bc_value_fn, nu
     for s in range(num_steps):
         g = np.asarray(bc_value_fn((s + 1) * dt), dtype=np.float64)
         b = M @ u - Al @ g
+        if source_fn is not None:
+            b = b + dt * (M1 @ np.asarray(source_fn((s + 1) * dt), dtype=np.float64))
         b[bc_nodes] = g
         u = lu.solve(b)
         out.append(u.copy())

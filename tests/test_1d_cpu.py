@@ -20,8 +20,13 @@ def test_run_1d_matches_the_oracle_slab_solver(tmp_path):
     coords, tris, tags, tag_map = prepare_mesh(cfg, mesh_folder, True, stack)     # stock 2-D mesh
     with pytest.raises(FileNotFoundError):
         r1.run_1d(cfg, str(tmp_path / "nope"), use_radial_correction=False)
-    with pytest.raises(NotImplementedError):
-        r1.run_1d(cfg, mesh_folder)                                                # correction is f3
+    # default use_radial_correction=True with no gradient CSV around: switched off, like the reference
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        res0 = r1.run_1d(cfg, mesh_folder, output_folder=str(tmp_path / "o0"), write_xdmf=False, suppress_print=True)
+    finally:
+        os.chdir(cwd)
     wp = watcher_points(cfg)
     out = str(tmp_path / "out")
     res = r1.run_1d(cfg, mesh_folder, output_folder=out, watcher_points=wp, write_xdmf=False, suppress_print=True,
@@ -49,3 +54,34 @@ def test_run_1d_matches_the_oracle_slab_solver(tmp_path):
     assert os.path.isfile(os.path.join(out, "watcher_points.csv")) and os.path.isfile(os.path.join(out, "used_config.yaml"))
     wn = int(np.argmin(np.abs(z - wp["oside"][0])))
     assert res["watchers"]["oside"][-1] == pytest.approx(ref[-1][wn], abs=1e-8)
+    assert np.array_equal(res0["u"], res["u"])
+
+    # f3: radial-loss source from a gradient CSV (synthetic table in the layout run_no_diamond writes)
+    from scipy.interpolate import RegularGridInterpolator
+    g_t = np.linspace(0.0, 7.5e-6, 11)
+    g_z = np.linspace(-3.9e-6, 6.9e-6, 40)                      # narrower than the mesh: the ends get clamped
+    g_v = -2.0e8 * np.outer(g_t / g_t[-1], np.exp(-((g_z + 0.9e-6) / 1.5e-6) ** 2))
+    csvp = tmp_path / "radial_gradient.csv"
+    with open(csvp, "w") as f:
+        f.write("time," + ",".join(repr(float(v)) for v in g_z) + "\n")
+        for tt_, row in zip(g_t, g_v):
+            f.write(repr(float(tt_)) + "," + ",".join(repr(float(v)) for v in row) + "\n")
+    interp = RegularGridInterpolator((g_t, g_z), g_v)
+    zc = np.clip(z, g_z.min(), g_z.max())
+    for lookup in ("reference", "cell"):
+        resc = r1.run_1d(cfg, mesh_folder, output_folder=str(tmp_path / ("oc_" + lookup)), write_xdmf=False,
+                         suppress_print=True, use_radial_correction=True, radial_gradient_path=str(csvp),
+                         kappa_lookup=lookup)
+        cell_of_node = np.maximum(np.arange(len(z)) - 1, 0)
+        nk = kp[res["cell_tags"][cell_of_node]] if lookup == "reference" else kp[cell_of_node]
+
+        def source(t):
+            gv = interp(np.column_stack([np.full(len(z), min(max(t, g_t[0]), g_t[-1])), zc]))
+            gv[z != zc] *= 0.1
+            return 2.0 * nk * gv / 0.1e-6
+
+        refc = ho.solve_1d_slab(z, rc, kp, dt, np.full(len(z), 300.0), bc_nodes,
+                                lambda t: np.array([300.0, ho.heating_amplitude(t, h_time, h_temp, 300.0), 300.0]), 50,
+                                source_fn=source)
+        assert np.abs(resc["u"] - refc[-1]).max() < 1e-7
+        assert np.abs(resc["u"] - res["u"]).max() > 1.0           # the correction really acts

@@ -154,3 +154,81 @@ def test_scale_reaches_one_million_dof_band():
     n1 = build_case("geballe_with_diamond", 4.0)[2].stats["n_nodes"]
     n2 = build_case("geballe_with_diamond", 2.0)[2].stats["n_nodes"]
     assert 3.3 < n2 / n1 < 4.3
+
+
+MSH41 = """$MeshFormat
+4.1 0 8
+$EndMeshFormat
+$PhysicalNames
+2
+2 7 "left_mat"
+2 9 "right_mat"
+$EndPhysicalNames
+$Entities
+6 7 2 0
+1 0 0 0 0
+2 1 0 0 0
+3 1 1 0 0
+4 0 1 0 0
+5 2 0 0 0
+6 2 1 0 0
+1 0 0 0 1 0 0 0 2 1 -2
+2 1 0 0 1 1 0 0 2 2 -3
+3 0 1 0 1 1 0 0 2 3 -4
+4 0 0 0 0 1 0 0 2 4 -1
+5 1 0 0 2 0 0 0 2 2 -5
+6 2 0 0 2 1 0 0 2 5 -6
+7 1 1 0 2 1 0 0 2 6 -3
+1 0 0 0 1 1 0 1 7 4 1 2 3 4
+2 1 0 0 2 1 0 1 9 4 5 6 7 -2
+$EndEntities
+$Nodes
+8 6 1 6
+0 1 0 1
+1
+0 0 0
+0 2 0 1
+2
+1 0 0
+0 3 0 1
+3
+1 1 0
+0 4 0 1
+4
+0 1 0
+0 5 0 1
+5
+2 0 0
+0 6 0 1
+6
+2 1 0
+2 1 0 0
+2 2 0 0
+$EndNodes
+$Elements
+3 5 1 5
+1 2 1 1
+1 2 3
+2 1 2 2
+2 1 2 3
+3 1 3 4
+2 2 2 2
+4 2 5 6
+5 2 6 3
+$EndElements
+"""
+
+
+def test_msh41_ascii_reader(tmp_path):
+    """A reference-generated mesh.msh (MSH 4.1, physical groups per surface) can be fed in."""
+    path = tmp_path / "mesh41.msh"
+    path.write_text(MSH41)
+    coords, tris, tags = read_msh(str(path))
+    assert coords.shape == (6, 2) and tris.shape == (4, 3)
+    assert tags.tolist() == [7, 7, 9, 9]                       # physical group of the owning surface
+    assert np.allclose(coords[tris[2]], [[1, 0], [2, 0], [2, 1]])
+    from heatflow_amd.mesh import MeshError
+    bad = tmp_path / "bin.msh"
+    bad.write_text("$MeshFormat\n4.1 1 8\n$EndMeshFormat\n")
+    with pytest.raises(MeshError, match="binary"):
+        read_msh(str(bad))
