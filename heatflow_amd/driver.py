@@ -258,26 +258,50 @@ def write_watcher_csv(path, times, names, watchers):
 
 
 class _FieldWriter:
-    """Stand-in for the XDMF time series (reference :414-424, :483-484; h5py is not available):
-    ``output_fields.f64`` (raw float64, one field per step, initial state first) +
-    ``output_fields.json`` (times, n) + ``output_mesh.npz``."""
+    """``output.xdmf`` time series (reference :414-424, :483-484 via dolfinx.io.XDMFFile).
+    dolfinx stores the heavy data in HDF5; h5py is not available here, so the same XDMF 3 layout
+    (mesh grid + temporal collection of the nodal attribute "Temperature (K)") points at raw
+    little-endian binary files instead (``Format="Binary"``, readable by ParaView/VisIt):
+    ``output_xy.bin`` (n x 2 float64), ``output_conn.bin`` (n_e x 3 int32) and
+    ``output_fields.f64`` (one field per step, initial state first, addressed with ``Seek``)."""
 
     def __init__(self, folder, coords, tris, tags):
-        self.path = os.path.join(folder, "output_fields.f64")
-        self.meta = os.path.join(folder, "output_fields.json")
-        np.savez(os.path.join(folder, "output_mesh.npz"), coords=coords, tris=tris, tags=tags)
-        self.f = open(self.path, "wb")
+        self.folder = folder
+        self.n, self.ne = len(coords), len(tris)
+        np.ascontiguousarray(coords, dtype="<f8").tofile(os.path.join(folder, "output_xy.bin"))
+        np.ascontiguousarray(tris, dtype="<i4").tofile(os.path.join(folder, "output_conn.bin"))
+        np.ascontiguousarray(tags, dtype="<i4").tofile(os.path.join(folder, "output_cell_tags.bin"))
+        self.f = open(os.path.join(folder, "output_fields.f64"), "wb")
         self.times = []
-        self.n = len(coords)
 
     def __call__(self, t, u):
-        np.asarray(u, dtype=np.float64).tofile(self.f)
+        np.asarray(u, dtype="<f8").tofile(self.f)
         self.times.append(float(t))
 
     def close(self):
         self.f.close()
-        with open(self.meta, "w") as f:
-            json.dump({"name": "Temperature (K)", "n": self.n, "times": self.times, "dtype": "float64"}, f)
+        n, ne = self.n, self.ne
+        item = 'Format="Binary" Endian="Little"'
+        out = ['<?xml version="1.0"?>', '<Xdmf Version="3.0" xmlns:xi="http://www.w3.org/2001/XInclude">', " <Domain>",
+               '  <Grid Name="mesh" GridType="Uniform">',
+               f'   <Topology TopologyType="Triangle" NumberOfElements="{ne}" NodesPerElement="3">',
+               f'    <DataItem {item} DataType="Int" Precision="4" Dimensions="{ne} 3">output_conn.bin</DataItem>',
+               "   </Topology>", '   <Geometry GeometryType="XY">',
+               f'    <DataItem {item} DataType="Float" Precision="8" Dimensions="{n} 2">output_xy.bin</DataItem>',
+               "   </Geometry>", "  </Grid>",
+               '  <Grid Name="Temperature (K)" GridType="Collection" CollectionType="Temporal">']
+        for k, t in enumerate(self.times):
+            out += ['   <Grid Name="Temperature (K)" GridType="Uniform">',
+                    "    <xi:include xpointer=\"xpointer(/Xdmf/Domain/Grid[@GridType='Uniform'][1]/*[self::Topology or self::Geometry])\" />",
+                    f'    <Time Value="{t!r}" />',
+                    '    <Attribute Name="Temperature (K)" AttributeType="Scalar" Center="Node">',
+                    f'     <DataItem {item} DataType="Float" Precision="8" Seek="{8 * n * k}" Dimensions="{n} 1">output_fields.f64</DataItem>',
+                    "    </Attribute>", "   </Grid>"]
+        out += ["  </Grid>", " </Domain>", "</Xdmf>"]
+        with open(os.path.join(self.folder, "output.xdmf"), "w") as f:
+            f.write("\n".join(out) + "\n")
+        with open(os.path.join(self.folder, "output_fields.json"), "w") as f:
+            json.dump({"name": "Temperature (K)", "n": n, "times": self.times, "dtype": "float64"}, f)
 
 
 def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_mesh=False, output_folder=None,

@@ -68,6 +68,16 @@ def test_run_simulation_outputs_and_mesh_cache(tmp_path, module, name):
     assert np.allclose(res2["watchers"]["a"], res["watchers"]["pside"], rtol=0, atol=1e-9)
     meta = json.load(open(os.path.join(out, "output_fields.json")))
     assert len(meta["times"]) == 9 and os.path.getsize(os.path.join(out, "output_fields.f64")) == 9 * 8 * meta["n"]
+    import xml.etree.ElementTree as ET
+    root = ET.parse(os.path.join(out, "output.xdmf")).getroot()            # well-formed XDMF 3, binary heavy data
+    grids = root.findall("./Domain/Grid")
+    assert grids[0].find("Topology").get("TopologyType") == "Triangle" and grids[1].get("CollectionType") == "Temporal"
+    steps = grids[1].findall("Grid")
+    assert len(steps) == 9 and float(steps[0].find("Time").get("Value")) == 0.0
+    last = steps[-1].find("Attribute/DataItem")
+    assert last.get("Format") == "Binary" and int(last.get("Seek")) == 8 * 8 * meta["n"]
+    fld = np.fromfile(os.path.join(out, "output_fields.f64"), dtype="<f8").reshape(9, meta["n"])
+    assert (fld[0] == 300.0).all() and np.abs(fld[-1] - 300.0).max() > 0.1
     with pytest.raises(ValueError, match="watcher_points must be a dict or list of dicts"):
         run.run_simulation(cfg, mesh_folder, watcher_points=3, backend=OracleBackend())
 
