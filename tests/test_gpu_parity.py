@@ -319,3 +319,36 @@ def test_entry_points_end_to_end_on_gpu(hip, tmp_path, module, name):
         got_last = np.array(raw[-1][1:], dtype=float)
         assert np.abs(got_last - g_last).max() <= 1e-4 * max(np.abs(g_last).max(), 1.0) + 1e-3
         assert os.path.isfile(os.path.join(out, "radial_gradient.csv"))
+
+
+def test_kappa_sweep_on_gpu_reuses_mesh_and_hierarchy(hip, tmp_path):
+    """sweep_test.py analogue on the real backend (world of 1): one session, three kappa values;
+    every point must match an oracle run of the same cfg, with the multigrid levels built once."""
+    import copy
+
+    from conftest import HEATING_CSV, load_cfg
+    from heatflow_amd import parameter_sweep as ps
+    from heatflow_amd.geometry import scale_mesh_sizes, watcher_points
+    from heatflow_amd.mesh import load_mesh_arrays
+    from heatflow_amd.solver import nearest_nodes
+    from oracle import heat_oracle as ho
+    import yaml, os
+
+    cfg = scale_mesh_sizes(load_cfg("geballe_with_diamond"), 8.0)
+    cfg["heating"]["file"] = HEATING_CSV
+    cfg["timing"]["num_steps"] = 10
+    cfg["timing"]["t_final"] = 10 * 7.5e-8
+    mesh_folder, out = str(tmp_path / "mesh"), str(tmp_path / "out")
+    rows = ps.run_kappa_sweep(cfg, mesh_folder, [3.3, 3.8, 4.3], out, rebuild_mesh=True)
+    assert [r["status"] for r in rows] == ["success"] * 3 and [r["k"] for r in rows] == [3.3, 3.8, 4.3]
+    coords, tris, tags = load_mesh_arrays(os.path.join(mesh_folder, "mesh.msh"))
+    mtags = yaml.safe_load(open(os.path.join(mesh_folder, "mesh_cfg.yaml")))["material_tags"]
+    nodes = nearest_nodes(coords, list(watcher_points(cfg).values()))
+    for k in (3.3, 4.3):
+        c = copy.deepcopy(cfg)
+        c["mats"]["p_sample"]["k"] = k
+        ref = ho.run_reference_algorithm(c, coords, tris, tags, mtags, HEATING_CSV, watcher_nodes=nodes)
+        got = np.genfromtxt(os.path.join(out, f"{k:.2f}", "watcher_points.csv"), delimiter=",", names=True)
+        assert np.abs(got["oside"] - ref["watchers"][:, 1]).max() <= FIELD_TOL_K
+        assert np.abs(got["pside"] - ref["watchers"][:, 0]).max() <= FIELD_TOL_K
+    assert os.path.isfile(os.path.join(out, "rmse_summary.csv"))
