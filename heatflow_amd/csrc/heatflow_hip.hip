@@ -19,6 +19,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -31,8 +32,8 @@ namespace {
 constexpr int RB = 256;        // CSR rows owned by one workgroup (assembly, SpMV chunk)
 constexpr int TPB = 256;       // threads per workgroup = 4 wavefronts of 64
 constexpr int NCOL = 32;       // max colours per row block (uint32 mask)
-#ifndef HF_SPMV_VARIANT
-#define HF_SPMV_VARIANT 1
+#ifndef HF_UNROLL
+#define HF_UNROLL 4
 #endif
 constexpr int MAXP = 1024;     // max workgroups per launch = partial-sum slots per array
 constexpr int TS = 512;        // SpMV workgroup: 512 threads = 8 wavefronts own 512 consecutive rows per chunk
@@ -119,6 +120,11 @@ struct hf_ctx {
   bool flux_ready = false;
   double *d_M1 = nullptr, *d_dinv1 = nullptr, *d_gz = nullptr, *d_gr = nullptr, *d_bz = nullptr, *d_br = nullptr;
   int pred_flux[2] = {0, 0};
+  // hipGraph replay of the PCG loops: one executable graph per (system, preconditioner), each holding
+  // an even number of iterations (all host-side pointer swaps return to their start after two)
+  struct IterGraph { const double* A; const double* dinv; double* x; const double* b; bool amg; int iters; hipGraphExec_t exec; };
+  std::vector<IterGraph> graphs;
+  bool use_graph = true;
   // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
@@ -500,16 +506,17 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
     const int r1 = min(n, r0 + rpc);
     const int k0 = rowptr[r0];
     const int k1 = rowptr[r1];
-    if (MODE != 7) {  // products in nnz order; 4 independent value/index loads and gathers in flight per lane
+    if (MODE != 7) {  // products in nnz order; HF_UNROLL independent value/index loads and gathers in flight per lane
       int k = k0 + threadIdx.x;
-      for (; k + 3 * TS < k1; k += 4 * TS) {
-        const int c0 = colidx[k], c1 = colidx[k + TS], c2 = colidx[k + 2 * TS], c3 = colidx[k + 3 * TS];
-        const double v0 = vals[k], v1 = vals[k + TS], v2 = vals[k + 2 * TS], v3 = vals[k + 3 * TS];
-        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-        sprod[k - k0] = v0 * x0;
-        sprod[k - k0 + TS] = v1 * x1;
-        sprod[k - k0 + 2 * TS] = v2 * x2;
-        sprod[k - k0 + 3 * TS] = v3 * x3;
+      for (; k + (HF_UNROLL - 1) * TS < k1; k += HF_UNROLL * TS) {
+        int c[HF_UNROLL];
+        double v[HF_UNROLL], xv[HF_UNROLL];
+#pragma unroll
+        for (int u = 0; u < HF_UNROLL; ++u) { c[u] = colidx[k + u * TS]; v[u] = vals[k + u * TS]; }
+#pragma unroll
+        for (int u = 0; u < HF_UNROLL; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < HF_UNROLL; ++u) sprod[k - k0 + u * TS] = v[u] * xv[u];
       }
       for (; k < k1; k += TS) sprod[k - k0] = vals[k] * x[colidx[k]];
     }
@@ -1000,7 +1007,10 @@ using DevLevel = hf_ctx::DevLevel;
 
 void free_dev_csr(DevCsr& m) { dev_free(&m.ptr); dev_free(&m.idx); dev_free(&m.val); m = DevCsr(); }
 
+void drop_graphs(hf_ctx* ctx);
+
 void free_amg(hf_ctx* ctx) {
+  drop_graphs(ctx);
   for (size_t l = 0; l < ctx->amg.size(); ++l) {
     DevLevel& L = ctx->amg[l];
     if (l > 0) { free_dev_csr(L.A); dev_free(&L.dinv); dev_free(&L.x); dev_free(&L.b); }
@@ -1205,6 +1215,44 @@ int read_scal(hf_ctx* ctx) {
   return HF_OK;
 }
 
+void drop_graphs(hf_ctx* ctx) {
+  for (auto& g : ctx->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  ctx->graphs.clear();
+}
+
+// Executable graph holding `iters` (even) consecutive iterations of the loop for `sys`; captured on
+// first use, replayed afterwards.  Returns nullptr when capture is unavailable (the caller then
+// launches eagerly).
+hipGraphExec_t iteration_graph(hf_ctx* ctx, const LinSys& sys, bool use_amg, int iters) {
+  for (auto& g : ctx->graphs)
+    if (g.A == sys.A && g.dinv == sys.dinv && g.x == sys.x && g.b == sys.b && g.amg == use_amg && g.iters == iters)
+      return g.exec;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  const bool dbg = std::getenv("HEATFLOW_DEBUG") != nullptr;
+  if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    if (dbg) fprintf(stderr, "[heatflow] graph capture could not start\n");
+    return nullptr;
+  }
+  for (int k = 0; k < iters; ++k) {
+    if (use_amg) launch_amg_iteration(ctx, k & 1);
+    else launch_pcg_iteration(ctx, sys, k & 1);
+  }
+  if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || graph == nullptr) {
+    if (dbg) fprintf(stderr, "[heatflow] graph capture failed\n");
+    return nullptr;
+  }
+  const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  size_t nnodes = 0;
+  (void)hipGraphGetNodes(graph, nullptr, &nnodes);
+  (void)hipGraphDestroy(graph);
+  if (dbg) fprintf(stderr, "[heatflow] graph of %d iterations: %zu nodes, instantiate %s\n", iters, nnodes, hipGetErrorString(e));
+  if (e != hipSuccess) return nullptr;
+  ctx->graphs.push_back({sys.A, sys.dinv, sys.x, sys.b, use_amg, iters, exec});
+  return exec;
+}
+
 // PCG on `sys` started from sys.x.  Jacobi: any system on the pattern; AMG: the main system only.
 // Iteration count / residual are left in h_scal; *pred carries the burst-size hint between calls.
 int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double atol, int max_it, int* pred) {
@@ -1234,12 +1282,20 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
   }
   // first burst: what the previous solve needed (the counts drift slowly), then check in small bursts
   int burst = std::max(2, std::min(max_it, *pred > 0 ? *pred : (use_amg ? 8 : 32)));
+  // graph unit: 2 multigrid iterations (~40 kernels) or 16 Jacobi iterations (48 kernels) per replay
+  const int unit = use_amg ? 2 : 16;
+  hipGraphExec_t gexec = (ctx->use_graph && !ctx->prof) ? iteration_graph(ctx, sys, use_amg, unit) : nullptr;
   while (true) {
     burst += burst & 1;  // parity pairs
     ctx->prof_base = launched;
-    for (int k = 0; k < burst; ++k) {
-      if (use_amg) launch_amg_iteration(ctx, (launched + k) & 1);
-      else launch_pcg_iteration(ctx, sys, (launched + k) & 1);
+    if (gexec != nullptr) {
+      burst = ((burst + unit - 1) / unit) * unit;
+      for (int k = 0; k < burst; k += unit) HF_HIP(hipGraphLaunch(gexec, ctx->stream));
+    } else {
+      for (int k = 0; k < burst; ++k) {
+        if (use_amg) launch_amg_iteration(ctx, (launched + k) & 1);
+        else launch_pcg_iteration(ctx, sys, (launched + k) & 1);
+      }
     }
     launched += burst;
     HF_HIP(hipGetLastError());
@@ -1264,10 +1320,9 @@ int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
   // pass writes the extrapolated start vector 2 u^n - u^{n-1}, and the three state buffers rotate
   if (ctx->extrapolate && ctx->have_prev) {
     launch_spmv<8>(ctx, ctx->d_M, ctx->d_u, ctx->d_b, nullptr, ctx->d_uprev, ctx->d_ustart);
-    double* old_prev = ctx->d_uprev;
-    ctx->d_uprev = ctx->d_u;        // u^n
-    ctx->d_u = ctx->d_ustart;       // iterate, becomes u^{n+1}
-    ctx->d_ustart = old_prev;
+    // u^{n-1} <- u^n, iterate <- start vector (copies, not pointer rotation: captured graphs hold d_u)
+    HF_HIP(hipMemcpyAsync(ctx->d_uprev, ctx->d_u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+    HF_HIP(hipMemcpyAsync(ctx->d_u, ctx->d_ustart, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
   } else {
     launch_spmv<0>(ctx, ctx->d_M, ctx->d_u, ctx->d_b);
     if (ctx->extrapolate) {         // keep u^n for the next step
@@ -1370,6 +1425,7 @@ int hf_create(int device_id, hf_ctx** out) {
   if (rc == HF_OK) rc = dev_alloc(ctx, &ctx->d_part_zz, MAXP);
   if (rc == HF_OK) rc = dev_alloc(ctx, &ctx->d_part_bn, MAXP);
   if (rc == HF_OK && hipMemset(ctx->d_scal, 0, sizeof(Scal)) != hipSuccess) rc = fail(ctx, HF_ERR_HIP, "hipMemset failed");
+  if (const char* e = std::getenv("HEATFLOW_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
   *out = ctx;
   return rc;
 }
@@ -1388,6 +1444,7 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_M1); dev_free(&ctx->d_dinv1); dev_free(&ctx->d_gz); dev_free(&ctx->d_gr); dev_free(&ctx->d_bz); dev_free(&ctx->d_br);
   dev_free(&ctx->d_tmp); dev_free(&ctx->d_part_pAp); dev_free(&ctx->d_part_rz); dev_free(&ctx->d_part_zz);
   dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp);
+  drop_graphs(ctx);
   for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1582,6 +1639,7 @@ int hf_flux_setup(hf_ctx* ctx) {
   if (!ctx->have_mesh) return fail(ctx, HF_ERR_STATE, "hf_flux_setup before hf_set_mesh");
   HF_HIP(hipSetDevice(ctx->dev));
   const int n = ctx->n;
+  drop_graphs(ctx);
   HF_TRY(dev_alloc(ctx, &ctx->d_M1, ctx->nnz));
   HF_TRY(dev_alloc(ctx, &ctx->d_dinv1, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_gz, n));
