@@ -188,7 +188,7 @@ def main():
     spmv_bytes = 12 * nnz + 20 * n
     from heatflow_amd import hip_backend as hb
     k_us = {nm: 1e3 * be.time_kernel(k, 100) for nm, k in
-            (("spmv", hb.K_PCG_SPMV), ("update", hb.K_PCG_UPDATE), ("dir", hb.K_PCG_DIR))}
+            (("spmv", hb.K_PCG_SPMV), ("update", hb.K_PCG_UPDATE), ("plain_spmv", hb.K_SPMV))}
     if spmv_us is None:
         spmv_us = k_us["spmv"]
     achieved = spmv_bytes / (spmv_us * 1e-6) / 1e9

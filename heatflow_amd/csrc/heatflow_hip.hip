@@ -45,6 +45,7 @@ struct Scal {                  // device-resident PCG scalars
   double zz;                   // ||D^-1 r||^2 of the last iterate
   int iters;
   int done;                    // 0 running, 1 converged, 2 breakdown
+  int first;                   // 1 until the first update of a solve: the first direction is p = z (beta = 0)
 };
 
 }  // namespace
@@ -485,6 +486,8 @@ __global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* 
 //           the products gather w*dinv[col]*b[col], so p is never read back)
 //   MODE 8: y = A x; p = 2 x - b        (RHS b = M u^n fused with the extrapolated start
 //           2 u^n - u^{n-1} of the next solve; `b` carries u^{n-1})
+//   MODE 9: PCG iteration head (x = z): convergence test, beta, Ap <- A z + beta Ap, p <- z + beta p,
+//           p.Ap partials - SpMV and direction update in one pass
 // The chunk is `rpc` rows (512 for the fine operator; fewer for long-row transfer operators so
 // that a chunk's products fit the 64-KB LDS window).
 // ------------------------------------------------------------------------------------------
@@ -492,15 +495,42 @@ template <int MODE>
 __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows per chunk, <= TS */,
                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                               const double* __restrict__ vals, const double* __restrict__ x,
-                                              double* __restrict__ y, const Scal* __restrict__ scal,
+                                              double* __restrict__ y, Scal* __restrict__ scal,
                                               double* __restrict__ part0, const double* __restrict__ bvec,
                                               const double* __restrict__ dinv, double* __restrict__ pvec,
                                               double* __restrict__ part1, double* __restrict__ part2, double w,
-                                              int npart /* partial slots the consumers sum (>= gridDim.x) */) {
+                                              int npart /* partial slots the consumers sum (>= gridDim.x) */,
+                                              int parity) {
   extern __shared__ double sprod[];
   __shared__ double s4[TS / 64];
-  if ((MODE == 1 || MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7) && scal->done) return;
+  if ((MODE == 1 || MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 9) && scal->done) return;
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  double beta = 0.0;
+  bool first9 = false;
+  if (MODE == 9) {
+    first9 = scal->first != 0;
+    // PCG iteration head: x = z (preconditioned residual).  Convergence test on the (D^-1 r)^2 partials
+    // of the last update, beta = r.z(new)/r.z(old) from the two parity slots (part1), then in the row
+    // loop  Ap <- A z + beta Ap,  p <- z + beta p  (direction update by recurrence) and p.Ap partials.
+    if (!first9) {
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+      for (int k = threadIdx.x; k < npart; k += TS) {
+        v0 += part1[parity * MAXP + k];
+        v1 += part1[(parity ^ 1) * MAXP + k];
+        v2 += part2[k];
+      }
+      const double rz_new = block_sum<TS / 64>(v0, s4);
+      const double rz_old = block_sum<TS / 64>(v1, s4);
+      const double zz = block_sum<TS / 64>(v2, s4);
+      const bool conv = zz <= scal->tol2;
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal->zz = zz;
+        if (conv) scal->done = 1;
+      }
+      if (conv) return;
+      beta = rz_new / rz_old;
+    }
+  }
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const int r0 = chunk * rpc;
     const int r1 = min(n, r0 + rpc);
@@ -566,15 +596,21 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
         const double bi = bvec[row];
         pvec[row] = w * dinv[row] * bi;
         y[row] = bi - s;
-      } else {
+      } else if (MODE == 8) {
         y[row] = s;
         pvec[row] = 2.0 * x[row] - bvec[row];
+      } else {
+        const double api = first9 ? s : s + beta * y[row];          // first iteration: p = z, Ap = A z
+        const double pi = first9 ? x[row] : x[row] + beta * pvec[row];
+        y[row] = api;
+        pvec[row] = pi;
+        acc0 += pi * api;
       }
     }
     __syncthreads();
   }
   // consumers sum `npart` slots in a fixed order; this launch has fewer workgroups, the rest are zeros
-  if (MODE == 1 || MODE == 2 || (MODE == 4 && part0 != nullptr)) {
+  if (MODE == 1 || MODE == 2 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {
     const double t0 = block_sum<TS / 64>(acc0, s4);
     if (threadIdx.x == 0) {
       part0[blockIdx.x] = t0;
@@ -604,6 +640,7 @@ __global__ __launch_bounds__(TPB) void k_pcg_begin(int P, double rtol, double at
     scal->bn2 = bn2;
     scal->zz = zz;
     scal->iters = 0;
+    scal->first = 1;
     scal->done = (zz <= tol * tol) ? 1 : 0;
   }
 }
@@ -613,7 +650,8 @@ __global__ __launch_bounds__(TPB) void k_pcg_update(int n, int nchunks, int P, i
                                                     const double* __restrict__ part_pAp, double* __restrict__ part_rz,
                                                     double* __restrict__ part_zz, double* __restrict__ x,
                                                     double* __restrict__ r, const double* __restrict__ p,
-                                                    const double* __restrict__ Ap, const double* __restrict__ dinv) {
+                                                    const double* __restrict__ Ap, const double* __restrict__ dinv,
+                                                    double* __restrict__ z) {
   __shared__ double s4[4];
   if (scal->done) return;
   const double pAp = sum_partials(part_pAp, P, s4);
@@ -622,6 +660,7 @@ __global__ __launch_bounds__(TPB) void k_pcg_update(int n, int nchunks, int P, i
     if (blockIdx.x == 0 && threadIdx.x == 0) scal->done = 2;
     return;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scal->iters += 1; scal->first = 0; }
   const double alpha = rz / pAp;
   double a_rz = 0.0, a_zz = 0.0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -631,6 +670,7 @@ __global__ __launch_bounds__(TPB) void k_pcg_update(int n, int nchunks, int P, i
       const double zi = dinv[i] * ri;
       x[i] += alpha * p[i];
       r[i] = ri;
+      z[i] = zi;
       a_rz += ri * zi;
       a_zz += zi * zi;
     }
@@ -642,31 +682,6 @@ __global__ __launch_bounds__(TPB) void k_pcg_update(int n, int nchunks, int P, i
     part_zz[blockIdx.x] = t1;
   }
 }
-
-// convergence test, beta = rz_new/rz_old, p = z + beta p
-__global__ __launch_bounds__(TPB) void k_pcg_dir(int n, int nchunks, int P, int parity, Scal* __restrict__ scal,
-                                                 const double* __restrict__ part_rz, const double* __restrict__ part_zz,
-                                                 const double* __restrict__ r, double* __restrict__ p,
-                                                 const double* __restrict__ dinv) {
-  __shared__ double s4[4];
-  if (scal->done) return;
-  const double rz_old = sum_partials(part_rz + parity * MAXP, P, s4);
-  const double rz_new = sum_partials(part_rz + (parity ^ 1) * MAXP, P, s4);
-  const double zz = sum_partials(part_zz, P, s4);
-  const bool conv = zz <= scal->tol2;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    scal->zz = zz;
-    scal->iters += 1;
-    if (conv) scal->done = 1;
-  }
-  if (conv) return;
-  const double beta = rz_new / rz_old;
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int i = chunk * RB + threadIdx.x;
-    if (i < n) p[i] = dinv[i] * r[i] + beta * p[i];
-  }
-}
-
 
 // ------------------------------------------------------------------------------------------
 // Generic CSR SpMV for the multigrid transfer operators and coarse levels: LANES lanes of a
@@ -773,6 +788,7 @@ __global__ __launch_bounds__(TPB) void k_pcg_update_amg(int n, int nchunks, int 
     if (blockIdx.x == 0 && threadIdx.x == 0) scal->done = 2;
     return;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scal->iters += 1; scal->first = 0; }
   const double alpha = rz / pAp;
   double a_zz = 0.0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -790,32 +806,6 @@ __global__ __launch_bounds__(TPB) void k_pcg_update_amg(int n, int nchunks, int 
   if (threadIdx.x == 0) part_zz[blockIdx.x] = t1;
 }
 
-// AMG-PCG: convergence test on (D^-1 r)^2, beta = rz_new/rz_old, p = z + beta p (first: p = z).
-__global__ __launch_bounds__(TPB) void k_pcg_dir_amg(int n, int nchunks, int P, int parity, int first,
-                                                     Scal* __restrict__ scal, const double* __restrict__ part_rz,
-                                                     const double* __restrict__ part_zz, const double* __restrict__ z,
-                                                     double* __restrict__ p) {
-  __shared__ double s4[4];
-  if (scal->done) return;
-  double beta = 0.0;
-  if (!first) {
-    const double rz_old = sum_partials(part_rz + parity * MAXP, P, s4);
-    const double rz_new = sum_partials(part_rz + (parity ^ 1) * MAXP, P, s4);
-    const double zz = sum_partials(part_zz, P, s4);
-    const bool conv = zz <= scal->tol2;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      scal->zz = zz;
-      scal->iters += 1;
-      if (conv) scal->done = 1;
-    }
-    if (conv) return;
-    beta = rz_new / rz_old;
-  }
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int i = chunk * RB + threadIdx.x;
-    if (i < n) p[i] = first ? z[i] : z[i] + beta * p[i];
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // host side: sparsity pattern, owner lists, colouring
@@ -963,19 +953,19 @@ template <int MODE>
 void launch_spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr,
                  const double* bvec = nullptr, double* pvec = nullptr, double* part1 = nullptr,
                  double* part2 = nullptr, double w = 0.0, const double* dinv = nullptr, hipEvent_t ev_start = nullptr,
-                 hipEvent_t ev_stop = nullptr) {
+                 hipEvent_t ev_stop = nullptr, int parity = 0) {
   // With events: the launch carries them (hipExtLaunchKernelGGL), so they bracket the kernel's own
   // execution on the device - the same interval rocprofv3 reports - not the launch gap before it.
   if (ev_start != nullptr)
     hipExtLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), static_cast<std::uint32_t>(spmv_smem_bytes(c)), c->stream,
                           ev_start, ev_stop, 0u, c->n, c->nchunks_s, static_cast<int>(TS),
                           static_cast<const int32_t*>(c->d_rowptr), static_cast<const int32_t*>(c->d_colidx), vals, x, y,
-                          static_cast<const Scal*>(c->d_scal), part0, bvec, dinv ? dinv : static_cast<const double*>(c->d_dinv),
-                          pvec, part1, part2, w, c->P);
+                          c->d_scal, part0, bvec, dinv ? dinv : static_cast<const double*>(c->d_dinv),
+                          pvec, part1, part2, w, c->P, parity);
   else
     hipLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), spmv_smem_bytes(c), c->stream, c->n, c->nchunks_s, TS,
                        c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, dinv ? dinv : c->d_dinv, pvec, part1,
-                       part2, w, c->P);
+                       part2, w, c->P, parity);
 }
 
 constexpr int PROF_PAIRS = 64;
@@ -983,21 +973,16 @@ constexpr int PROF_PAIRS = 64;
 // A linear system on the context's sparsity pattern: values, inverse diagonal, unknown, right-hand side.
 struct LinSys { const double* A; const double* dinv; double* x; const double* b; };
 
+// One Jacobi-PCG iteration = 2 kernels: [convergence, beta, Ap/p by recurrence, p.Ap] + [alpha, x, r, z, r.z, z.z]
 void launch_pcg_iteration(hf_ctx* c, const LinSys& s, int parity) {
   const bool timed = c->prof && c->prof_used < PROF_PAIRS;
-  if (timed) {
-    launch_spmv<1>(c, s.A, c->d_p, c->d_Ap, c->d_part_pAp, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr,
-                   c->prof_ev[2 * c->prof_used], c->prof_ev[2 * c->prof_used + 1]);
-    c->prof_used++;
-  } else {
-    launch_spmv<1>(c, s.A, c->d_p, c->d_Ap, c->d_part_pAp);
-  }
+  hipEvent_t e0 = timed ? c->prof_ev[2 * c->prof_used] : nullptr, e1 = timed ? c->prof_ev[2 * c->prof_used + 1] : nullptr;
+  launch_spmv<9>(c, s.A, c->d_z, c->d_Ap, c->d_part_pAp, nullptr, c->d_p, c->d_part_rz, c->d_part_zz, 0.0, nullptr, e0, e1,
+                 parity);
+  if (timed) c->prof_used++;
   hipLaunchKernelGGL(k_pcg_update, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
-                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, s.x, c->d_r, c->d_p, c->d_Ap, s.dinv);
-  hipLaunchKernelGGL(k_pcg_dir, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
-                     c->d_part_rz, c->d_part_zz, c->d_r, c->d_p, s.dinv);
+                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, s.x, c->d_r, c->d_p, c->d_Ap, s.dinv, c->d_z);
 }
-
 
 // ------------------------------------------------------------------------------------------
 // multigrid: hierarchy upload, V-cycle, AMG-PCG step
@@ -1126,7 +1111,7 @@ void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y, const do
     const int grid = std::min(m.nchunks, MAXP);
     hipLaunchKernelGGL(k_spmv<SM>, dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream, m.nrow,
                        m.nchunks, m.rpc, m.ptr, m.idx, m.val, x, y, c->d_scal, static_cast<double*>(nullptr), b, dinv,
-                       xout, static_cast<double*>(nullptr), static_cast<double*>(nullptr), w, 0);
+                       xout, static_cast<double*>(nullptr), static_cast<double*>(nullptr), w, 0, 0);
     return;
   }
   const int lanes = m.lanes;
@@ -1143,14 +1128,16 @@ void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y, const do
 #undef HF_VEC
 }
 
-// z = B r: one V(1,1) cycle.  On entry d_z holds w0 D^-1 r (written by the update / start kernel);
-// on exit d_z holds the result and part_rz[out_slot] the partials of r.z.
+// z = B r: one V(1,1) cycle.  Fixed buffer roles (no pointer swaps, so captured graphs and eager
+// launches always agree): on entry d_z holds w0 D^-1 r (written by the update / start kernel); on exit
+// d_z2 holds z and part_rz[out_slot] the partials of r.z.  On every coarser level x carries the
+// pre-smoothed iterate plus the coarse correction and x2 the post-smoothed result (the coarsest
+// level's result is its x).
 void vcycle(hf_ctx* c, int out_slot) {
   const int nl = static_cast<int>(c->amg.size());
   DevLevel& L0 = c->amg[0];
   if (nl == 1) {  // no coarse level: one more Jacobi sweep keeps the operator symmetric
     launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
-    std::swap(c->d_z, c->d_z2);
     return;
   }
   launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r);                 // t = r - A z
@@ -1172,30 +1159,25 @@ void vcycle(hf_ctx* c, int out_slot) {
   }
   for (int l = nl - 2; l >= 1; --l) {
     DevLevel& L = c->amg[l];
-    launch_vec<1>(c, L.P, c->amg[l + 1].x, L.x);                                // x_l += P_l x_{l+1}
-    launch_vec<3>(c, L.A, L.x, L.x2, L.b, L.dinv, L.omega);                     // post-smooth
-    std::swap(L.x, L.x2);
+    const double* coarse = (l + 1 == nl - 1) ? c->amg[l + 1].x : c->amg[l + 1].x2;
+    launch_vec<1>(c, L.P, coarse, L.x);                                         // x_l += P_l x_{l+1}
+    launch_vec<3>(c, L.A, L.x, L.x2, L.b, L.dinv, L.omega);                     // post-smooth -> x2
   }
-  launch_vec<1>(c, L0.P, c->amg[1].x, c->d_z);                                  // z += P0 x_1
+  launch_vec<1>(c, L0.P, (nl == 2) ? c->amg[1].x : c->amg[1].x2, c->d_z);       // z += P0 x_1
   launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
-  std::swap(c->d_z, c->d_z2);
 }
 
+// One multigrid-PCG iteration: iteration head (as above), update (alpha, x, r, z0 = w D^-1 r), V-cycle (z, r.z)
 void launch_amg_iteration(hf_ctx* c, int parity) {
   const bool timed = c->prof && c->prof_used < PROF_PAIRS;
-  if (timed) {
-    launch_spmv<1>(c, c->d_A, c->d_p, c->d_Ap, c->d_part_pAp, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr,
-                   c->prof_ev[2 * c->prof_used], c->prof_ev[2 * c->prof_used + 1]);
-    c->prof_used++;
-  } else {
-    launch_spmv<1>(c, c->d_A, c->d_p, c->d_Ap, c->d_part_pAp);
-  }
+  hipEvent_t e0 = timed ? c->prof_ev[2 * c->prof_used] : nullptr, e1 = timed ? c->prof_ev[2 * c->prof_used + 1] : nullptr;
+  launch_spmv<9>(c, c->d_A, c->d_z2, c->d_Ap, c->d_part_pAp, nullptr, c->d_p, c->d_part_rz, c->d_part_zz, 0.0, nullptr, e0,
+                 e1, parity);
+  if (timed) c->prof_used++;
   hipLaunchKernelGGL(k_pcg_update_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
                      c->d_part_pAp, c->d_part_rz, c->d_part_zz, c->d_u, c->d_r, c->d_p, c->d_Ap, c->d_dinv,
                      c->amg[0].omega, c->d_z);
   vcycle(c, parity ^ 1);
-  hipLaunchKernelGGL(k_pcg_dir_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, 0, c->d_scal,
-                     c->d_part_rz, c->d_part_zz, c->d_z, c->d_p);
 }
 
 int read_scal(hf_ctx* ctx) {
@@ -1257,21 +1239,19 @@ hipGraphExec_t iteration_graph(hf_ctx* ctx, const LinSys& sys, bool use_amg, int
 // Iteration count / residual are left in h_scal; *pred carries the burst-size hint between calls.
 int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double atol, int max_it, int* pred) {
   if (!use_amg) {
-    // r = b - A x, p = z = D^-1 r
-    launch_spmv<2>(ctx, sys.A, sys.x, ctx->d_r, ctx->d_part_rz, sys.b, ctx->d_p, ctx->d_part_zz, ctx->d_part_bn, 0.0,
+    // r = b - A x, z = D^-1 r, r.z
+    launch_spmv<2>(ctx, sys.A, sys.x, ctx->d_r, ctx->d_part_rz, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn, 0.0,
                    sys.dinv);
     hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
                        ctx->d_part_bn, ctx->d_scal);
   } else {
-    // r = b - A x, z0 = w D^-1 r; tolerance; z = B r (V-cycle, r.z into slot 0); p = z
+    // r = b - A x, z0 = w D^-1 r; tolerance; z = B r (V-cycle, r.z into slot 0)
     HF_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(Scal), ctx->stream));   // done = 0 so the start kernels run
     launch_spmv<5>(ctx, sys.A, sys.x, ctx->d_r, nullptr, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn,
                    ctx->amg[0].omega);
     hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
                        ctx->d_part_bn, ctx->d_scal);
     vcycle(ctx, 0);
-    hipLaunchKernelGGL(k_pcg_dir_amg, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, ctx->nchunks, ctx->P, 0, 1,
-                       ctx->d_scal, ctx->d_part_rz, ctx->d_part_zz, ctx->d_z, ctx->d_p);
   }
   HF_HIP(hipGetLastError());
 
@@ -1840,17 +1820,18 @@ int hf_time_kernel(hf_ctx* ctx, int32_t which, int32_t reps, double* ms_avg) {
       switch (which) {
         case HF_K_SPMV: launch_spmv<0>(ctx, ctx->d_A, ctx->d_tmp, ctx->d_Ap); break;
         case HF_K_RHS: launch_spmv<0>(ctx, ctx->d_M, ctx->d_tmp, ctx->d_b); break;
-        case HF_K_PCG_SPMV: launch_spmv<1>(ctx, ctx->d_A, ctx->d_tmp, ctx->d_Ap, ctx->d_part_pAp); break;
+        case HF_K_PCG_SPMV:  // iteration head as in the loop (beta = 1 from the benign partials set below)
+          launch_spmv<9>(ctx, ctx->d_A, ctx->d_tmp, ctx->d_Ap, ctx->d_part_pAp, nullptr, ctx->d_p, ctx->d_part_rz,
+                         ctx->d_part_zz);
+          break;
         case HF_K_PCG_UPDATE:
           // alpha from whatever the partial slots hold: make them benign (pAp = P, rz = 0 -> alpha = 0)
           hipLaunchKernelGGL(k_pcg_update, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, ctx->nchunks, ctx->P, 0,
                              ctx->d_scal, ctx->d_part_bn, ctx->d_part_rz, ctx->d_part_zz, ctx->d_r, ctx->d_p,
-                             ctx->d_tmp, ctx->d_Ap, ctx->d_dinv);
+                             ctx->d_tmp, ctx->d_Ap, ctx->d_dinv, ctx->d_z);
           break;
         case HF_K_PCG_DIR:
-          hipLaunchKernelGGL(k_pcg_dir, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, ctx->nchunks, ctx->P, 0,
-                             ctx->d_scal, ctx->d_part_rz, ctx->d_part_zz, ctx->d_r, ctx->d_p, ctx->d_dinv);
-          break;
+          return fail(ctx, HF_ERR_ARG, "HF_K_PCG_DIR: the direction update is fused into the PCG SpMV (HF_K_PCG_SPMV)");
         case HF_K_ASSEMBLE: HF_TRY(launch_assemble(ctx)); break;
         default: return fail(ctx, HF_ERR_ARG, "hf_time_kernel: unknown kernel %d", which);
       }
@@ -1858,8 +1839,10 @@ int hf_time_kernel(hf_ctx* ctx, int32_t which, int32_t reps, double* ms_avg) {
     HF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     HF_HIP(hipGetLastError());
     HF_HIP(hipStreamSynchronize(ctx->stream));
-    if (pass == 0 && (which == HF_K_PCG_UPDATE || which == HF_K_PCG_DIR)) {
+    if (pass == 0 && (which == HF_K_PCG_UPDATE || which == HF_K_PCG_SPMV)) {
       // benign scalars for the timed pass: p.Ap partials = 1, r.z partials = tiny, tol2 = 0, not done
+      HF_HIP(hipMemset(ctx->d_p, 0, sizeof(double) * ctx->n));
+      HF_HIP(hipMemset(ctx->d_Ap, 0, sizeof(double) * ctx->n));
       std::vector<double> ones(MAXP, 1.0), tiny(2 * MAXP, 1e-300);
       HF_HIP(hipMemcpy(ctx->d_part_bn, ones.data(), sizeof(double) * MAXP, hipMemcpyHostToDevice));
       HF_HIP(hipMemcpy(ctx->d_part_rz, tiny.data(), sizeof(double) * 2 * MAXP, hipMemcpyHostToDevice));

@@ -64,9 +64,9 @@ enum { HF_ASM_LDS_ATOMIC = 0, HF_ASM_LDS_COLORED = 1, HF_ASM_GLOBAL_ATOMIC = 2 }
 /* Kernels addressable by hf_time_kernel */
 enum {
   HF_K_SPMV = 0,        /* y = A x, CSR, LDS-staged products            */
-  HF_K_PCG_SPMV = 1,    /* Ap = A p with fused p.Ap partial sums        */
+  HF_K_PCG_SPMV = 1,    /* PCG iteration head: beta, Ap <- A z + beta Ap, p <- z + beta p, p.Ap partials */
   HF_K_PCG_UPDATE = 2,  /* x += a p; r -= a Ap; z = D^-1 r; r.z, z.z    */
-  HF_K_PCG_DIR = 3,     /* p = z + b p                                  */
+  HF_K_PCG_DIR = 3,     /* retired: the direction update is fused into HF_K_PCG_SPMV (returns HF_ERR_ARG) */
   HF_K_ASSEMBLE = 4,    /* element kernel in the mode of the last hf_assemble */
   HF_K_RHS = 5          /* b = M u^n                                    */
 };

@@ -11,7 +11,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     prob = make_problem(cfg, stack, mesh, precond=int(sys.argv[3]))
     be = prob.backend
     out = {}
-    for nm, k in (("spmv", hb.K_SPMV), ("pcg_spmv", hb.K_PCG_SPMV), ("update", hb.K_PCG_UPDATE), ("dir", hb.K_PCG_DIR)):
+    for nm, k in (("spmv", hb.K_SPMV), ("pcg_spmv", hb.K_PCG_SPMV), ("update", hb.K_PCG_UPDATE)):
         out[nm] = round(min(be.time_kernel(k, 200) for _ in range(3)) * 1e3, 2)
     t, s, it = prob.run(16, time_varying=[prob.bcs[3]])
     out["ms_per_step_16"] = round(be.last_gpu_ms() / 16, 3); out["iters"] = int(np.sum(it))

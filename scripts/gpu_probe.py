@@ -25,8 +25,8 @@ ms = be.last_gpu_ms()
 print("run %d steps: %.2f ms total, %.3f ms/step, iters %s" % (nsteps, ms, ms / nsteps, list(iters)), flush=True)
 tot_it = int(np.sum(iters))
 print("  per PCG iteration (incl. rhs etc): %.2f us" % (1e3 * ms / max(tot_it, 1)))
-names = {hb.K_SPMV: ("spmv", 12 * nnz + 20 * n), hb.K_PCG_SPMV: ("pcg_spmv", 12 * nnz + 28 * n), hb.K_PCG_UPDATE: ("pcg_update", 56 * n),
-         hb.K_PCG_DIR: ("pcg_dir", 32 * n), hb.K_RHS: ("rhs", 12 * nnz + 20 * n)}
+names = {hb.K_SPMV: ("spmv", 12 * nnz + 20 * n), hb.K_PCG_SPMV: ("pcg_spmv", 12 * nnz + 52 * n), hb.K_PCG_UPDATE: ("pcg_update", 64 * n),
+         hb.K_RHS: ("rhs", 12 * nnz + 20 * n)}
 for k, (nm, byt) in names.items():
     t = be.time_kernel(k, 200)
     print("  %-11s %8.2f us  %7.1f GB/s (algorithmic %d B)" % (nm, t * 1e3, byt / t / 1e6, byt), flush=True)
