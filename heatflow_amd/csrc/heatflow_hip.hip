@@ -114,7 +114,7 @@ struct hf_ctx {
   struct DevLevel { DevCsr A, P, R; double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr; double omega = 0; int n = 0; };
   std::vector<DevLevel> amg;
   double* d_coarse_inv = nullptr;
-  int coarse_n = 0;
+  int coarse_n = 0, coarse_ld = 0;   // dense inverse, row-major with an even leading dimension (16-byte row loads)
   double amg_opc = 0.0, amg_setup_s = 0.0;
   double *d_z = nullptr, *d_z2 = nullptr;
   // read-flux projection (hf_flux_setup): unit-rho_c r-weighted mass matrix and the projected gradient
@@ -726,22 +726,37 @@ __global__ __launch_bounds__(TPB) void k_scale(int n, double w, const double* __
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) x[i] = w * dinv[i] * b[i];
 }
 
-// x = Ainv b with the dense inverse of the coarsest operator: one wavefront per row.
-__global__ __launch_bounds__(TPB) void k_dense_mv(int n, const double* __restrict__ Ainv, const double* __restrict__ b,
-                                                  double* __restrict__ x, const Scal* __restrict__ scal) {
+// x = Ainv b with the dense inverse of the coarsest operator (row-major, leading dimension ld, even):
+// two wavefronts per row, 16-byte loads, halves combined through LDS.
+__global__ __launch_bounds__(TPB) void k_dense_mv(int n, int ld, const double* __restrict__ Ainv,
+                                                  const double* __restrict__ b, double* __restrict__ x,
+                                                  const Scal* __restrict__ scal) {
+  __shared__ double half_sum[4];
   if (scal->done) return;
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * TPB) >> 6;
-  for (int row = wave; row < n; row += nwaves) {
+  const int wave = threadIdx.x >> 6;            // 0..3: waves 0,1 -> row 2*blk, waves 2,3 -> row 2*blk + 1
+  const int npair = (n + 1) >> 1;
+  for (int pr = blockIdx.x; pr < npair; pr += gridDim.x) {
+    const int row = 2 * pr + (wave >> 1);
     double s = 0.0;
-    for (int j = lane; j < n; j += 64) s += Ainv[static_cast<size_t>(row) * n + j] * b[j];
+    if (row < n) {
+      const double2* arow = reinterpret_cast<const double2*>(Ainv + static_cast<size_t>(row) * ld);
+      const double2* bv = reinterpret_cast<const double2*>(b);
+      const int nv = ld >> 1;
+      for (int j = (wave & 1) * 64 + lane; j < nv; j += 128) {
+        const double2 a = arow[j];
+        const double2 v = bv[j];
+        s += a.x * v.x + a.y * v.y;
+      }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (lane == 0) x[row] = s;
+    if (lane == 0) half_sum[wave] = s;
+    __syncthreads();
+    if (lane == 0 && (wave & 1) == 0 && row < n) x[row] = half_sum[wave] + half_sum[wave + 1];
+    __syncthreads();
   }
 }
-
 
 // Dense inverse of the coarsest operator on the GPU: Gauss-Jordan without pivoting (the operator
 // is SPD, its pivots stay positive).  Two launches per pivot; A is overwritten by the identity.
@@ -1060,10 +1075,11 @@ int build_amg(hf_ctx* ctx) {
       HF_TRY(upload_csr(ctx, hl.A, L.A));
       HF_TRY(dev_alloc(ctx, &L.dinv, L.n));
       HF_HIP(hipMemcpy(L.dinv, hl.dinv.data(), sizeof(double) * L.n, hipMemcpyHostToDevice));
-      HF_TRY(dev_alloc(ctx, &L.x, L.n));
-      HF_TRY(dev_alloc(ctx, &L.b, L.n));
-      HF_TRY(dev_alloc(ctx, &L.x2, L.n));
-      HF_TRY(dev_alloc(ctx, &L.r, L.n));
+      HF_TRY(dev_alloc(ctx, &L.x, L.n + 2));
+      HF_TRY(dev_alloc(ctx, &L.b, L.n + 2));
+      HF_TRY(dev_alloc(ctx, &L.x2, L.n + 2));
+      HF_TRY(dev_alloc(ctx, &L.r, L.n + 2));
+      HF_HIP(hipMemset(L.b, 0, sizeof(double) * (L.n + 2)));   // the dense solve reads b in pairs
     }
     if (l + 1 < nl) { HF_TRY(upload_csr(ctx, hl.P, L.P)); HF_TRY(upload_csr(ctx, hl.R, L.R)); }
   }
@@ -1071,28 +1087,35 @@ int build_amg(hf_ctx* ctx) {
   ctx->coarse_n = 0;
   if (nl > 1 && H.coarse_n > 0 && H.coarse_n <= 4096) {
     const int nc = H.coarse_n;
+    const int ld = (nc + 1) & ~1;
     const amg::Csr& Ac = H.levels.back().A;
     std::vector<double> dense(static_cast<size_t>(nc) * nc, 0.0), eye(static_cast<size_t>(nc) * nc, 0.0);
     for (int i = 0; i < nc; ++i) {
       for (int k = Ac.ptr[i]; k < Ac.ptr[i + 1]; ++k) dense[static_cast<size_t>(i) * nc + Ac.idx[k]] = Ac.val[k];
       eye[static_cast<size_t>(i) * nc + i] = 1.0;
     }
-    double *d_dense = nullptr, *d_prow = nullptr, *d_pcol = nullptr;
+    double *d_dense = nullptr, *d_inv = nullptr, *d_prow = nullptr, *d_pcol = nullptr;
     HF_TRY(dev_alloc(ctx, &d_dense, dense.size()));
-    HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv, eye.size()));
+    HF_TRY(dev_alloc(ctx, &d_inv, eye.size()));
+    HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv, static_cast<size_t>(nc) * ld));
     HF_TRY(dev_alloc(ctx, &d_prow, 2 * static_cast<size_t>(nc)));
     HF_TRY(dev_alloc(ctx, &d_pcol, static_cast<size_t>(nc)));
     HF_HIP(hipMemcpy(d_dense, dense.data(), sizeof(double) * dense.size(), hipMemcpyHostToDevice));
-    HF_HIP(hipMemcpy(ctx->d_coarse_inv, eye.data(), sizeof(double) * eye.size(), hipMemcpyHostToDevice));
+    HF_HIP(hipMemcpy(d_inv, eye.data(), sizeof(double) * eye.size(), hipMemcpyHostToDevice));
     const int gp = std::max(1, (nc + TPB - 1) / TPB);
     const int ge = static_cast<int>(std::min<size_t>((static_cast<size_t>(nc) * nc + TPB - 1) / TPB, 4096));
     for (int cpiv = 0; cpiv < nc; ++cpiv) {
-      hipLaunchKernelGGL(k_gj_pivot, dim3(gp), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, ctx->d_coarse_inv, d_prow, d_pcol);
-      hipLaunchKernelGGL(k_gj_elim, dim3(ge), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, ctx->d_coarse_inv, d_prow, d_pcol);
+      hipLaunchKernelGGL(k_gj_pivot, dim3(gp), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, d_inv, d_prow, d_pcol);
+      hipLaunchKernelGGL(k_gj_elim, dim3(ge), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, d_inv, d_prow, d_pcol);
     }
     HF_HIP(hipGetLastError());
+    // rows re-pitched to the even leading dimension (zero pad column)
+    HF_HIP(hipMemsetAsync(ctx->d_coarse_inv, 0, sizeof(double) * nc * ld, ctx->stream));
+    HF_HIP(hipMemcpy2DAsync(ctx->d_coarse_inv, sizeof(double) * ld, d_inv, sizeof(double) * nc, sizeof(double) * nc, nc,
+                            hipMemcpyDeviceToDevice, ctx->stream));
     HF_HIP(hipStreamSynchronize(ctx->stream));
-    dev_free(&d_dense); dev_free(&d_prow); dev_free(&d_pcol);
+    dev_free(&d_dense); dev_free(&d_inv); dev_free(&d_prow); dev_free(&d_pcol);
+    ctx->coarse_ld = ld;
     ctx->coarse_n = nc;
   }
   ctx->amg_opc = H.op_complexity;
@@ -1150,8 +1173,9 @@ void vcycle(hf_ctx* c, int out_slot) {
   {
     DevLevel& Lc = c->amg[nl - 1];
     if (c->coarse_n > 0) {
-      const int g = std::max(1, std::min((Lc.n * 64 + TPB - 1) / TPB, 1024));
-      hipLaunchKernelGGL(k_dense_mv, dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->d_coarse_inv, Lc.b, Lc.x, c->d_scal);
+      const int g = std::max(1, std::min((Lc.n + 1) / 2, 2048));
+      hipLaunchKernelGGL(k_dense_mv, dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv, Lc.b, Lc.x,
+                         c->d_scal);
     } else {
       const int g = std::max(1, std::min((Lc.n + TPB - 1) / TPB, 1024));
       hipLaunchKernelGGL(k_scale, dim3(g), dim3(TPB), 0, c->stream, Lc.n, Lc.omega, Lc.dinv, Lc.b, Lc.x, c->d_scal);
