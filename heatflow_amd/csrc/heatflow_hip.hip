@@ -29,7 +29,11 @@
 
 namespace {
 
-constexpr int RB = 256;        // CSR rows owned by one workgroup (assembly, SpMV chunk)
+constexpr int RB = 256;        // rows per chunk of the vector kernels
+#ifndef HF_RBA
+#define HF_RBA 256
+#endif
+constexpr int RBA = HF_RBA;    // CSR rows owned by one assembly workgroup (= its thread count); 512 measured 7 % slower
 constexpr int TPB = 256;       // threads per workgroup = 4 wavefronts of 64
 constexpr int NCOL = 32;       // max colours per row block (uint32 mask)
 #ifndef HF_UNROLL
@@ -78,7 +82,8 @@ struct hf_ctx {
   // device: pattern + owner lists
   int32_t *d_rowptr = nullptr, *d_colidx = nullptr;
   int32_t *d_blk_eptr = nullptr, *d_blk_cptr = nullptr;
-  int4 *d_blk_ent = nullptr, *d_blk_el = nullptr;
+  int2* d_blk_ent = nullptr;     // 3 x int2 per owner-list entry
+  int nblk_a = 0;
   int max_blk_nnz = 0, ncolors = 0;
   int64_t elist_len = 0;
   // device: matrices
@@ -231,7 +236,7 @@ __device__ __forceinline__ int sym_index(int a, int b) {  // (a,b) -> slot in {0
 }
 
 // ------------------------------------------------------------------------------------------
-// Assembly, LDS-staged owner-computes.  Workgroup `blk` owns rows [blk*RB, blk*RB+RB): it
+// Assembly, LDS-staged owner-computes.  Workgroup `blk` owns rows [blk*RBA, blk*RBA+RBA): it
 // stages that slab of M and A (values) plus its column indices in LDS, walks the elements
 // incident to its rows (precomputed list; an element on a block boundary is visited by each
 // owning block, which adds only the rows it owns), and writes the slab out coalesced.
@@ -239,12 +244,22 @@ __device__ __forceinline__ int sym_index(int a, int b) {  // (a,b) -> slot in {0
 //   COLORED = true : elements grouped by colour (no two share an owned row), plain RMW,
 //                    barrier between colours -> bitwise reproducible
 // ------------------------------------------------------------------------------------------
+// One list entry = 24 bytes = three int2: (n0, n1) (n2, tag<<11 | owned<<8 | off8) (off0..3, off4..7):
+// the element record and the offsets of its nine contributions (a,b) = (0,0) (0,1) ... (2,2) inside
+// the CSR rows of its nodes; `owned` marks the nodes whose rows this workgroup owns.
+struct AsmEntry { int n0, n1, n2; unsigned w3, off03, off47; };
+
+__device__ __forceinline__ AsmEntry load_entry(const int2* __restrict__ ent, int q) {
+  const int2 a = ent[3 * q], b = ent[3 * q + 1], c = ent[3 * q + 2];
+  return AsmEntry{a.x, a.y, b.x, static_cast<unsigned>(b.y), static_cast<unsigned>(c.x), static_cast<unsigned>(c.y)};
+}
+
 template <bool COLORED>
-__global__ __launch_bounds__(TPB) void k_assemble_lds(int n, int cap, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(RBA) void k_assemble_lds(int n, int cap, const int32_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ blk_eptr,
                                                       const int32_t* __restrict__ blk_cptr,
-                                                      const int4* __restrict__ blk_ent,
-                                                      const int4* __restrict__ blk_el, const double2* __restrict__ zr,
+                                                      const int2* __restrict__ blk_ent,
+                                                      const double2* __restrict__ zr,
                                                       const double* __restrict__ kappa_tab,
                                                       const double* __restrict__ rhoc_tab, double dt,
                                                       double* __restrict__ Mv, double* __restrict__ Av) {
@@ -254,68 +269,58 @@ __global__ __launch_bounds__(TPB) void k_assemble_lds(int n, int cap, const int3
   int* sR = reinterpret_cast<int*>(smem + 2 * cap);
 
   const int blk = blockIdx.x;
-  const int r0 = blk * RB;
-  const int r1 = min(n, r0 + RB);
+  const int r0 = blk * RBA;
+  const int r1 = min(n, r0 + RBA);
   const int k0 = rowptr[r0];
   const int nk = rowptr[r1] - k0;
-  for (int k = threadIdx.x; k < nk; k += TPB) {
+  for (int k = threadIdx.x; k < nk; k += RBA) {
     sM[k] = 0.0;
     sA[k] = 0.0;
   }
-  for (int k = threadIdx.x; k <= r1 - r0; k += TPB) sR[k] = rowptr[r0 + k] - k0;
+  for (int k = threadIdx.x; k <= r1 - r0; k += RBA) sR[k] = rowptr[r0 + k] - k0;
   __syncthreads();
 
-  // One list entry = (element id, nine slot offsets inside the rows of its three nodes, ownership
-  // mask): x = element, y|z|w[7:0] = offsets of (a,b) = (0,0) (0,1) ... (2,2), w[10:8] = node a owned.
-  auto scatter = [&](const int4 ent, const int4 el, const double2 p0, const double2 p1, const double2 p2) {
+  auto scatter = [&](const AsmEntry e, const double2 p0, const double2 p1, const double2 p2) {
     double m[6], kk[6], av6[6];
-    element_local(p0, p1, p2, rhoc_tab[el.w], kappa_tab[el.w], m, kk);
+    const int tag = static_cast<int>(e.w3 >> 11);
+    element_local(p0, p1, p2, rhoc_tab[tag], kappa_tab[tag], m, kk);
 #pragma unroll
     for (int q = 0; q < 6; ++q) av6[q] = fma(dt, kk[q], m[q]);  // once per unique entry, explicit FMA: same bits everywhere
-    const int nd[3] = {el.x, el.y, el.z};
-    const unsigned pos03 = static_cast<unsigned>(ent.y), pos47 = static_cast<unsigned>(ent.z);
-    const unsigned pos8 = static_cast<unsigned>(ent.w);
+    const int nd[3] = {e.n0, e.n1, e.n2};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      if (!((pos8 >> (8 + a)) & 1u)) continue;
+      if (!((e.w3 >> (8 + a)) & 1u)) continue;
       const int base = sR[nd[a] - r0];
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         const int q9 = a * 3 + b;
-        const unsigned off = q9 < 4 ? (pos03 >> (8 * q9)) & 0xFFu : q9 < 8 ? (pos47 >> (8 * (q9 - 4))) & 0xFFu : pos8 & 0xFFu;
+        const unsigned off = q9 < 4 ? (e.off03 >> (8 * q9)) & 0xFFu : q9 < 8 ? (e.off47 >> (8 * (q9 - 4))) & 0xFFu : e.w3 & 0xFFu;
         const int slot = base + static_cast<int>(off);
         const int q = sym_index(a, b);
-        const double mv = m[q];
-        const double av = av6[q];
         if (COLORED) {
-          sM[slot] += mv;
-          sA[slot] += av;
+          sM[slot] += m[q];
+          sA[slot] += av6[q];
         } else {
-          atomicAdd(&sM[slot], mv);
-          atomicAdd(&sA[slot], av);
+          atomicAdd(&sM[slot], m[q]);
+          atomicAdd(&sA[slot], av6[q]);
         }
       }
     }
   };
-  // The list is laid out per workgroup: entry q = (offsets/mask, blk_ent[q]) + a copy of its element
-  // record (n0, n1, n2, tag; blk_el[q]) - both streamed coalesced, only the coordinates are gathered.
+  // The list is laid out per workgroup and streamed coalesced; only the coordinates are gathered.
   // Three elements in flight per lane: all loads are issued before the first scatter.
   constexpr int NF = 3;
   auto run_range = [&](int e0, int e1) {
-    for (int k = e0 + threadIdx.x; k < e1; k += NF * TPB) {
-      int4 ent[NF], el[NF];
+    for (int k = e0 + threadIdx.x; k < e1; k += NF * RBA) {
+      AsmEntry e[NF];
       double2 pa[NF], pb[NF], pc[NF];
 #pragma unroll
-      for (int u = 0; u < NF; ++u) {
-        const int q = min(k + u * TPB, e1 - 1);
-        ent[u] = blk_ent[q];
-        el[u] = blk_el[q];
-      }
+      for (int u = 0; u < NF; ++u) e[u] = load_entry(blk_ent, min(k + u * RBA, e1 - 1));
 #pragma unroll
-      for (int u = 0; u < NF; ++u) { pa[u] = zr[el[u].x]; pb[u] = zr[el[u].y]; pc[u] = zr[el[u].z]; }
+      for (int u = 0; u < NF; ++u) { pa[u] = zr[e[u].n0]; pb[u] = zr[e[u].n1]; pc[u] = zr[e[u].n2]; }
 #pragma unroll
       for (int u = 0; u < NF; ++u)
-        if (k + u * TPB < e1) scatter(ent[u], el[u], pa[u], pb[u], pc[u]);
+        if (k + u * RBA < e1) scatter(e[u], pa[u], pb[u], pc[u]);
     }
   };
 
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(TPB) void k_assemble_lds(int n, int cap, const int3
     run_range(blk_eptr[blk], blk_eptr[blk + 1]);
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < nk; k += TPB) {
+  for (int k = threadIdx.x; k < nk; k += RBA) {
     Mv[k0 + k] = sM[k];
     Av[k0 + k] = sA[k];
   }
@@ -372,24 +377,23 @@ __global__ __launch_bounds__(TPB) void k_assemble_global(int ne, const int32_t* 
 // onto vector P1 with the r-weighted mass matrix.  The reference solves one 2n x 2n system; the
 // components decouple into two scalar solves with M_r(1).  This kernel forms both right-hand
 // sides  b_c[i] = sum_e (d_c T)_e * int_e phi_i r dx,  int_e phi_i r = |K| (2 r_i + r_j + r_k)/12,
-// owner-computes like the assembly: a workgroup owns 256 rows and adds the incident elements.
+// owner-computes like the assembly: a workgroup owns RBA rows and adds the incident elements.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_grad_rhs(int n, const int32_t* __restrict__ blk_eptr,
-                                                  const int4* __restrict__ blk_ent, const int4* __restrict__ blk_el,
-                                                  const double2* __restrict__ zr, const double* __restrict__ u,
-                                                  double* __restrict__ bz, double* __restrict__ br) {
-  __shared__ double sB[2 * RB];
+__global__ __launch_bounds__(RBA) void k_grad_rhs(int n, const int32_t* __restrict__ blk_eptr,
+                                                  const int2* __restrict__ blk_ent, const double2* __restrict__ zr,
+                                                  const double* __restrict__ u, double* __restrict__ bz,
+                                                  double* __restrict__ br) {
+  __shared__ double sB[2 * RBA];
   const int blk = blockIdx.x;
-  const int r0 = blk * RB;
-  const int r1 = min(n, r0 + RB);
-  for (int k = threadIdx.x; k < 2 * RB; k += TPB) sB[k] = 0.0;
+  const int r0 = blk * RBA;
+  const int r1 = min(n, r0 + RBA);
+  for (int k = threadIdx.x; k < 2 * RBA; k += RBA) sB[k] = 0.0;
   __syncthreads();
-  for (int q = blk_eptr[blk] + threadIdx.x; q < blk_eptr[blk + 1]; q += TPB) {
+  for (int q = blk_eptr[blk] + threadIdx.x; q < blk_eptr[blk + 1]; q += RBA) {
 #pragma clang fp contract(off)
-    const int4 ent = blk_ent[q];
-    const int4 el = blk_el[q];
-    const double2 p0 = zr[el.x], p1 = zr[el.y], p2 = zr[el.z];
-    const double u0 = u[el.x], u1 = u[el.y], u2 = u[el.z];
+    const AsmEntry e = load_entry(blk_ent, q);
+    const double2 p0 = zr[e.n0], p1 = zr[e.n1], p2 = zr[e.n2];
+    const double u0 = u[e.n0], u1 = u[e.n1], u2 = u[e.n2];
     const double d = (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
     const double area = 0.5 * fabs(d);
     // grad phi_i = (b_i, c_i)/d
@@ -397,8 +401,8 @@ __global__ __launch_bounds__(TPB) void k_grad_rhs(int n, const int32_t* __restri
     const double gr = (u0 * (p2.x - p1.x) + u1 * (p0.x - p2.x) + u2 * (p1.x - p0.x)) / d;
     const double rsum = (p0.y + p1.y) + p2.y;
     const double wgt[3] = {area * (p0.y + rsum) / 12.0, area * (p1.y + rsum) / 12.0, area * (p2.y + rsum) / 12.0};
-    const int nd[3] = {el.x, el.y, el.z};
-    const unsigned owned = (static_cast<unsigned>(ent.w) >> 8) & 7u;
+    const int nd[3] = {e.n0, e.n1, e.n2};
+    const unsigned owned = (e.w3 >> 8) & 7u;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       if (!((owned >> a) & 1u)) continue;
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(TPB) void k_grad_rhs(int n, const int32_t* __restri
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < r1 - r0; k += TPB) {
+  for (int k = threadIdx.x; k < r1 - r0; k += RBA) {
     bz[r0 + k] = sB[2 * k];
     br[r0 + k] = sB[2 * k + 1];
   }
@@ -827,8 +831,7 @@ __global__ __launch_bounds__(TPB) void k_pcg_update_amg(int n, int nchunks, int 
 // ------------------------------------------------------------------------------------------
 struct Pattern {
   std::vector<int32_t> rowptr, colidx, blk_eptr, blk_cptr, blk_elist;
-  std::vector<int4> blk_ent;       // blk_elist entries widened with the nine slot offsets + ownership mask
-  std::vector<int4> blk_el;        // (n0, n1, n2, tag) of the same entries: a per-workgroup copy of the element records
+  std::vector<int2> blk_ent;       // 3 x int2 per list entry: element record + nine slot offsets + ownership mask
   int max_blk_nnz = 0, ncolors = 0;
 };
 
@@ -860,17 +863,17 @@ int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const 
     P.rowptr[i + 1] = static_cast<int32_t>(P.colidx.size());
   }
   // owner lists + greedy colouring per row block
-  const int nblk = (n + RB - 1) / RB;
+  const int nblk = (n + RBA - 1) / RBA;
   P.blk_eptr.assign(static_cast<size_t>(nblk) + 1, 0);
   P.blk_cptr.assign(static_cast<size_t>(nblk) * (NCOL + 1), 0);
   P.blk_elist.clear();
   P.blk_elist.reserve(static_cast<size_t>(ne) * 3 / 2);
   std::vector<int32_t> stamp(ne, -1), list, color;
-  std::vector<uint32_t> mask(RB);
+  std::vector<uint32_t> mask(RBA);
   P.max_blk_nnz = 0;
   P.ncolors = 0;
   for (int b = 0; b < nblk; ++b) {
-    const int32_t r0 = b * RB, r1 = std::min<int32_t>(n, r0 + RB);
+    const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
     P.max_blk_nnz = std::max(P.max_blk_nnz, P.rowptr[r1] - P.rowptr[r0]);
     list.clear();
     for (int32_t i = r0; i < r1; ++i)
@@ -911,10 +914,9 @@ int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const 
     P.blk_eptr[b + 1] = static_cast<int32_t>(P.blk_elist.size());
   }
   // widen every list entry with the offsets of its nine contributions inside the CSR rows
-  P.blk_ent.resize(P.blk_elist.size());
-  P.blk_el.resize(P.blk_elist.size());
+  P.blk_ent.resize(3 * P.blk_elist.size());
   for (int b = 0; b < nblk; ++b) {
-    const int32_t r0 = b * RB, r1 = std::min<int32_t>(n, r0 + RB);
+    const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
     for (int32_t q = P.blk_eptr[b]; q < P.blk_eptr[b + 1]; ++q) {
       const int32_t e = P.blk_elist[q];
       const int32_t nd[3] = {tri[3 * e], tri[3 * e + 1], tri[3 * e + 2]};
@@ -927,13 +929,12 @@ int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const 
         if (re - rb > 255) return fail(ctx, HF_ERR_ARG, "row %d holds more than 255 entries", nd[a]);
         for (int c = 0; c < 3; ++c) pos[a * 3 + c] = static_cast<uint32_t>(std::lower_bound(rb, re, nd[c]) - rb);
       }
-      int4 ent;
-      ent.x = e;
-      ent.y = static_cast<int>(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24));
-      ent.z = static_cast<int>(pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24));
-      ent.w = static_cast<int>(pos[8] | (owned << 8));
-      P.blk_ent[q] = ent;
-      P.blk_el[q] = make_int4(nd[0], nd[1], nd[2], tag[e]);
+      if (tag[e] >= (1 << 21)) return fail(ctx, HF_ERR_ARG, "cell tag %d does not fit the packed list entry (max 2^21 - 1)", tag[e]);
+      const uint32_t w3 = pos[8] | (owned << 8) | (static_cast<uint32_t>(tag[e]) << 11);
+      P.blk_ent[3 * q] = make_int2(nd[0], nd[1]);
+      P.blk_ent[3 * q + 1] = make_int2(nd[2], static_cast<int>(w3));
+      P.blk_ent[3 * q + 2] = make_int2(static_cast<int>(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24)),
+                                       static_cast<int>(pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24)));
     }
   }
   return HF_OK;
@@ -941,18 +942,30 @@ int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const 
 
 size_t spmv_smem_bytes(const hf_ctx* c) { return static_cast<size_t>(c->max_chunk_nnz_s) * 8; }
 
-int launch_assemble(hf_ctx* ctx) {
-  const int nblk = ctx->nchunks;
+// LDS-staged element kernel into (Mout, Aout) with the given coefficient tables.
+int launch_assemble_lds(hf_ctx* ctx, bool colored, const double* kappa_tab, const double* rhoc_tab, double dt,
+                        double* Mout, double* Aout) {
   const int cap = (ctx->max_blk_nnz + 1) & ~1;  // keep the int array 8-byte aligned
-  const size_t sm = static_cast<size_t>(cap) * 16 + (RB + 1) * 4;
-  if (ctx->mode == HF_ASM_LDS_COLORED) {
-    hipLaunchKernelGGL(k_assemble_lds<true>, dim3(nblk), dim3(TPB), sm, ctx->stream, ctx->n, cap, ctx->d_rowptr,
-                       ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_blk_el, ctx->d_zr,
-                       ctx->d_kappa, ctx->d_rhoc, ctx->dt, ctx->d_M, ctx->d_A);
-  } else if (ctx->mode == HF_ASM_LDS_ATOMIC) {
-    hipLaunchKernelGGL(k_assemble_lds<false>, dim3(nblk), dim3(TPB), sm, ctx->stream, ctx->n, cap, ctx->d_rowptr,
-                       ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_blk_el, ctx->d_zr,
-                       ctx->d_kappa, ctx->d_rhoc, ctx->dt, ctx->d_M, ctx->d_A);
+  const size_t sm = static_cast<size_t>(cap) * 16 + (RBA + 1) * 4;
+  if (sm > 64 * 1024) {  // beyond the default dynamic-LDS window: opt in (160 KB per CU on gfx950)
+    HF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_lds<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sm)));
+    HF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_lds<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sm)));
+  }
+  if (colored)
+    hipLaunchKernelGGL(k_assemble_lds<true>, dim3(ctx->nblk_a), dim3(RBA), sm, ctx->stream, ctx->n, cap, ctx->d_rowptr,
+                       ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_zr, kappa_tab, rhoc_tab, dt, Mout, Aout);
+  else
+    hipLaunchKernelGGL(k_assemble_lds<false>, dim3(ctx->nblk_a), dim3(RBA), sm, ctx->stream, ctx->n, cap, ctx->d_rowptr,
+                       ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_zr, kappa_tab, rhoc_tab, dt, Mout, Aout);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int launch_assemble(hf_ctx* ctx) {
+  if (ctx->mode == HF_ASM_LDS_COLORED || ctx->mode == HF_ASM_LDS_ATOMIC) {
+    return launch_assemble_lds(ctx, ctx->mode == HF_ASM_LDS_COLORED, ctx->d_kappa, ctx->d_rhoc, ctx->dt, ctx->d_M, ctx->d_A);
   } else {
     HF_HIP(hipMemsetAsync(ctx->d_M, 0, sizeof(double) * ctx->nnz, ctx->stream));
     HF_HIP(hipMemsetAsync(ctx->d_A, 0, sizeof(double) * ctx->nnz, ctx->stream));
@@ -1439,7 +1452,7 @@ int hf_destroy(hf_ctx* ctx) {
   (void)hipSetDevice(ctx->dev);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   dev_free(&ctx->d_zr); dev_free(&ctx->d_elem); dev_free(&ctx->d_kappa); dev_free(&ctx->d_rhoc);
-  dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent); dev_free(&ctx->d_blk_el); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
+  dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
   dev_free(&ctx->d_bc_dofs); dev_free(&ctx->d_g); dev_free(&ctx->d_lift_rows); dev_free(&ctx->d_lift_ptr);
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_uprev); dev_free(&ctx->d_ustart);
@@ -1476,6 +1489,7 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_TRY(build_pattern(ctx, n, ne, tri, tag, P));
   ctx->n = n; ctx->ne = ne; ctx->nnz = static_cast<int64_t>(P.colidx.size());
   ctx->nchunks = (n + RB - 1) / RB;
+  ctx->nblk_a = (n + RBA - 1) / RBA;
   ctx->P = std::min(ctx->nchunks, MAXP);
   ctx->nchunks_s = (n + TS - 1) / TS;
   ctx->Ps = std::min(ctx->nchunks_s, MAXP);
@@ -1485,7 +1499,7 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   ctx->max_blk_nnz = P.max_blk_nnz;
   ctx->ncolors = P.ncolors;
   ctx->elist_len = static_cast<int64_t>(P.blk_elist.size());
-  if (static_cast<size_t>((ctx->max_blk_nnz + 1) & ~1) * 16 + (RB + 1) * 4 > 64 * 1024)
+  if (static_cast<size_t>((ctx->max_blk_nnz + 1) & ~1) * 16 + (RBA + 1) * 4 > 160 * 1024)
     return fail(ctx, HF_ERR_ARG, "row block holds %d nonzeros: LDS slab too large", ctx->max_blk_nnz);
   ctx->tab_len = maxtag + 1;
   ctx->h_tag_used.assign(ctx->tab_len, 0);
@@ -1503,7 +1517,6 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_eptr, P.blk_eptr.size()));
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_cptr, P.blk_cptr.size()));
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_ent, P.blk_ent.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_blk_el, P.blk_el.size()));
   HF_TRY(dev_alloc(ctx, &ctx->d_M, ctx->nnz));
   HF_TRY(dev_alloc(ctx, &ctx->d_A, ctx->nnz));
   HF_TRY(dev_alloc(ctx, &ctx->d_dinv, n));
@@ -1525,8 +1538,7 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_HIP(hipMemcpy(ctx->d_colidx, P.colidx.data(), sizeof(int32_t) * ctx->nnz, hipMemcpyHostToDevice));
   HF_HIP(hipMemcpy(ctx->d_blk_eptr, P.blk_eptr.data(), sizeof(int32_t) * P.blk_eptr.size(), hipMemcpyHostToDevice));
   HF_HIP(hipMemcpy(ctx->d_blk_cptr, P.blk_cptr.data(), sizeof(int32_t) * P.blk_cptr.size(), hipMemcpyHostToDevice));
-  HF_HIP(hipMemcpy(ctx->d_blk_ent, P.blk_ent.data(), sizeof(int4) * P.blk_ent.size(), hipMemcpyHostToDevice));
-  HF_HIP(hipMemcpy(ctx->d_blk_el, P.blk_el.data(), sizeof(int4) * P.blk_el.size(), hipMemcpyHostToDevice));
+  HF_HIP(hipMemcpy(ctx->d_blk_ent, P.blk_ent.data(), sizeof(int2) * P.blk_ent.size(), hipMemcpyHostToDevice));
   HF_HIP(hipMemset(ctx->d_u, 0, sizeof(double) * n));
   ctx->h_rowptr.swap(P.rowptr);
   ctx->h_colidx.swap(P.colidx);
@@ -1658,11 +1670,7 @@ int hf_flux_setup(hf_ctx* ctx) {
   std::vector<double> ones(ctx->tab_len, 1.0), zeros(ctx->tab_len, 0.0);
   HF_HIP(hipMemcpy(d_one, ones.data(), sizeof(double) * ctx->tab_len, hipMemcpyHostToDevice));
   HF_HIP(hipMemcpy(d_zero, zeros.data(), sizeof(double) * ctx->tab_len, hipMemcpyHostToDevice));
-  const int cap = (ctx->max_blk_nnz + 1) & ~1;
-  const size_t sm = static_cast<size_t>(cap) * 16 + (RB + 1) * 4;
-  hipLaunchKernelGGL(k_assemble_lds<true>, dim3(ctx->nchunks), dim3(TPB), sm, ctx->stream, n, cap, ctx->d_rowptr,
-                     ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_blk_el, ctx->d_zr, d_zero, d_one, 0.0,
-                     ctx->d_M1, d_scratch);
+  HF_TRY(launch_assemble_lds(ctx, true, d_zero, d_one, 0.0, ctx->d_M1, d_scratch));
   hipLaunchKernelGGL(k_dinv, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ctx->d_rowptr, ctx->d_colidx,
                      ctx->d_M1, ctx->d_dinv1);
   HF_HIP(hipMemsetAsync(ctx->d_gz, 0, sizeof(double) * n, ctx->stream));
@@ -1681,8 +1689,8 @@ int hf_flux_project(hf_ctx* ctx, double rtol, int32_t max_it, double* grad_z, do
   if (max_it <= 0 || rtol < 0) return fail(ctx, HF_ERR_ARG, "hf_flux_project: bad tolerances");
   HF_HIP(hipSetDevice(ctx->dev));
   const int n = ctx->n;
-  hipLaunchKernelGGL(k_grad_rhs, dim3(ctx->nchunks), dim3(TPB), 0, ctx->stream, n, ctx->d_blk_eptr, ctx->d_blk_ent,
-                     ctx->d_blk_el, ctx->d_zr, ctx->d_u, ctx->d_bz, ctx->d_br);
+  hipLaunchKernelGGL(k_grad_rhs, dim3(ctx->nblk_a), dim3(RBA), 0, ctx->stream, n, ctx->d_blk_eptr, ctx->d_blk_ent,
+                     ctx->d_zr, ctx->d_u, ctx->d_bz, ctx->d_br);
   HF_HIP(hipGetLastError());
   // two scalar mass-matrix solves, each warm-started from the previous projection
   const LinSys sz{ctx->d_M1, ctx->d_dinv1, ctx->d_gz, ctx->d_bz};
