@@ -200,6 +200,31 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ part, 
   return block_sum(v, s4);
 }
 
+// Chunk schedule of the row-chunked kernels.  Workgroups are dealt round-robin over the 8 XCDs
+// (blockIdx % 8 says which blocks share an XCD and its L2; speed only, never correctness), so with
+// HF_XCD_MAP each XCD group walks one contiguous eighth of the chunk range: spatially adjacent chunks
+// (Morton order) then share an L2, which keeps the SpMV's neighbour gathers and a chunk's vector
+// slices from kernel to kernel on the same XCD.  Every kernel uses the same schedule.
+#ifndef HF_XCD_MAP
+#define HF_XCD_MAP 1
+#endif
+struct ChunkIter {
+  int chunk, step, end;
+  __device__ __forceinline__ ChunkIter(int nchunks) {
+    if (HF_XCD_MAP && (gridDim.x & 7) == 0) {
+      const int per = (nchunks + 7) >> 3;
+      const int xcd = blockIdx.x & 7;
+      chunk = xcd * per + (blockIdx.x >> 3);
+      step = gridDim.x >> 3;
+      end = min(nchunks, (xcd + 1) * per);
+    } else {
+      chunk = blockIdx.x;
+      step = gridDim.x;
+      end = nchunks;
+    }
+  }
+};
+
 // r-weighted P1 element matrices (reference forms run_with_diamond.py:328-331).
 //   M_ii = rho_c |K| (3 r_i + r_j + r_k)/30,  M_ij = rho_c |K| (2 r_i + 2 r_j + r_k)/60
 //   K_ij = kappa |K| rbar (b_i b_j + c_i c_j)/d^2, d = 2*signed area, rbar = mean r
@@ -535,7 +560,8 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
       beta = rz_new / rz_old;
     }
   }
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  const ChunkIter sched(nchunks);
+  for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
     const int r0 = chunk * rpc;
     const int r1 = min(n, r0 + rpc);
     const int k0 = rowptr[r0];
@@ -667,7 +693,8 @@ __global__ __launch_bounds__(TPB) void k_pcg_update(int n, int nchunks, int P, i
   if (blockIdx.x == 0 && threadIdx.x == 0) { scal->iters += 1; scal->first = 0; }
   const double alpha = rz / pAp;
   double a_rz = 0.0, a_zz = 0.0;
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  const ChunkIter sched(nchunks);
+  for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
     const int i = chunk * RB + threadIdx.x;
     if (i < n) {
       const double ri = r[i] - alpha * Ap[i];
@@ -810,7 +837,8 @@ __global__ __launch_bounds__(TPB) void k_pcg_update_amg(int n, int nchunks, int 
   if (blockIdx.x == 0 && threadIdx.x == 0) { scal->iters += 1; scal->first = 0; }
   const double alpha = rz / pAp;
   double a_zz = 0.0;
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  const ChunkIter sched(nchunks);
+  for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
     const int i = chunk * RB + threadIdx.x;
     if (i < n) {
       const double ri = r[i] - alpha * Ap[i];
@@ -1144,7 +1172,8 @@ void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y, const do
                 const double* dinv = nullptr, double w = 0.0, double* xout = nullptr) {
   if (m.rpc > 0) {
     constexpr int SM = VMODE == 0 ? 0 : VMODE == 1 ? 6 : VMODE == 2 ? 3 : VMODE == 3 ? 4 : 7;
-    const int grid = std::min(m.nchunks, MAXP);
+    int grid = std::min(m.nchunks, MAXP);
+    if (grid >= 64) grid &= ~7;
     hipLaunchKernelGGL(k_spmv<SM>, dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream, m.nrow,
                        m.nchunks, m.rpc, m.ptr, m.idx, m.val, x, y, c->d_scal, static_cast<double*>(nullptr), b, dinv,
                        xout, static_cast<double*>(nullptr), static_cast<double*>(nullptr), w, 0, 0);
@@ -1491,8 +1520,10 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   ctx->nchunks = (n + RB - 1) / RB;
   ctx->nblk_a = (n + RBA - 1) / RBA;
   ctx->P = std::min(ctx->nchunks, MAXP);
+  if (ctx->P >= 64) ctx->P &= ~7;          // multiple of 8: one equal group of workgroups per XCD
   ctx->nchunks_s = (n + TS - 1) / TS;
   ctx->Ps = std::min(ctx->nchunks_s, MAXP);
+  if (ctx->Ps >= 64) ctx->Ps &= ~7;
   ctx->max_chunk_nnz_s = 0;
   for (int c = 0; c < ctx->nchunks_s; ++c)
     ctx->max_chunk_nnz_s = std::max(ctx->max_chunk_nnz_s, P.rowptr[std::min<int64_t>(n, (c + 1LL) * TS)] - P.rowptr[c * TS]);
