@@ -12,9 +12,11 @@ refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
   sweep point (kappa_sample = 3.8 + 0.02*rank, the sweep_test.py grid) on the same mesh,
   which rank 0 builds and broadcasts over RCCL; no data-path collective.  value = all ranks'
   DOF-updates / max-over-ranks time ("weak" scaling).
-* roofline: the dominant kernel is the PCG CSR SpMV (k_spmv<1>).  achieved = algorithmic bytes
-  per launch (12*nnz + 20*n) / its average duration, measured in situ
-  with HIP event pairs on the solver's stream over extra steps right after the timed region.
+* roofline: the dominant kernel is the PCG iteration head k_spmv<9> (CSR SpMV A z with the direction
+  update p <- z + beta p, Ap <- A z + beta Ap fused).  achieved = algorithmic bytes per launch
+  (SpMV 12*nnz + 20*n of SURVEY.md section 8d, plus 24*n for reading the old p and Ap and writing p)
+  / its average duration, measured in situ with kernel-attached HIP events on the solver's stream
+  over extra steps right after the timed region.
 * cpu_baseline: the oracle (reference algorithm: assemble once, sparse LU once, two
   triangular solves per step; SciPy SuperLU, 1 thread) on the same mesh, rank 0, N = 1 only.
 """
@@ -185,7 +187,9 @@ def main():
         be.set_profile(False)
         if cnt > 0:
             spmv_us = 1e3 * ms_sum / cnt
-    spmv_bytes = 12 * nnz + 20 * n
+    # iteration-head kernel k_spmv<9>: vals 8 + colidx 4 per nnz; per row rowptr 4, z 8 (gathered operand),
+    # Ap 8+8 and p 8+8 (read-modify-write by the direction recurrence) = 12*nnz + 44*n
+    spmv_bytes = 12 * nnz + 44 * n
     from heatflow_amd import hip_backend as hb
     k_us = {nm: 1e3 * be.time_kernel(k, 100) for nm, k in
             (("spmv", hb.K_PCG_SPMV), ("update", hb.K_PCG_UPDATE), ("plain_spmv", hb.K_SPMV))}
@@ -199,7 +203,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
             pmc = json.load(f)
         if pmc["n"] == n and pmc["nnz"] == nnz:
-            traffic = pmc["kernels"]["k_spmv<1>"]["hbm_bytes"]
+            traffic = pmc["kernels"]["k_spmv<9>"]["hbm_bytes"]
     except (OSError, KeyError, ValueError):
         pass
 
@@ -236,7 +240,7 @@ def main():
                        "points": "1 sweep point per GPU (kappa_sample = 3.8 + 0.02*rank)" if world > 1 else "1 run",
                        "gpu_ms_per_step_events": gpu_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<1> (PCG CSR SpMV)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<9> (PCG iteration head: CSR SpMV with the direction update p, Ap fused)",
                          "bytes_per_launch": spmv_bytes, "us_per_launch": spmv_us,
                          "us_back_to_back": k_us},
         }

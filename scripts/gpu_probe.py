@@ -25,7 +25,7 @@ ms = be.last_gpu_ms()
 print("run %d steps: %.2f ms total, %.3f ms/step, iters %s" % (nsteps, ms, ms / nsteps, list(iters)), flush=True)
 tot_it = int(np.sum(iters))
 print("  per PCG iteration (incl. rhs etc): %.2f us" % (1e3 * ms / max(tot_it, 1)))
-names = {hb.K_SPMV: ("spmv", 12 * nnz + 20 * n), hb.K_PCG_SPMV: ("pcg_spmv", 12 * nnz + 52 * n), hb.K_PCG_UPDATE: ("pcg_update", 64 * n),
+names = {hb.K_SPMV: ("spmv", 12 * nnz + 20 * n), hb.K_PCG_SPMV: ("pcg_spmv", 12 * nnz + 44 * n), hb.K_PCG_UPDATE: ("pcg_update", 64 * n),
          hb.K_RHS: ("rhs", 12 * nnz + 20 * n)}
 for k, (nm, byt) in names.items():
     t = be.time_kernel(k, 200)

@@ -22,9 +22,8 @@ for kind, d in (("fetch", fetch_dir), ("write", write_dir)):
     for r in csv.DictReader(open(f)):
         acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     res[kind] = acc
-alg = {"k_spmv<1>": 12 * nnz + 20 * n, "k_spmv<0>": 12 * nnz + 20 * n, "k_spmv<3>": 12 * nnz + 28 * n,
-       "k_spmv<4>": 12 * nnz + 36 * n, "k_pcg_update_amg": 64 * n, "k_pcg_update": 56 * n, "k_pcg_dir": 32 * n,
-       "k_pcg_dir_amg": 24 * n, "k_assemble_lds<false>": 16 * ne + 16 * n + 16 * nnz}
+alg = {"k_spmv<9>": 12 * nnz + 44 * n, "k_spmv<1>": 12 * nnz + 20 * n, "k_spmv<0>": 12 * nnz + 20 * n, "k_spmv<3>": 12 * nnz + 28 * n,
+       "k_spmv<4>": 12 * nnz + 36 * n, "k_pcg_update_amg": 64 * n, "k_pcg_update": 64 * n, "k_spmv<8>": 12 * nnz + 36 * n, "k_assemble_lds<false>": 16 * ne + 16 * n + 16 * nnz}
 kern = {}
 with open(out + ".csv", "w") as f:
     f.write("kernel,launches,FETCH_SIZE_KB_p90,WRITE_SIZE_KB_p90,hbm_bytes_per_launch_corrected,algorithmic_bytes,ratio\n")
