@@ -25,6 +25,7 @@ import csv
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -39,14 +40,35 @@ from .solver import DEFAULT_MAX_IT, DEFAULT_RTOL, HeatProblem, nearest_nodes
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_quiet_lock = threading.Lock()
+_quiet_depth = 0
+_quiet_saved = None
+
+
 @contextlib.contextmanager
 def suppress_output(enabled):
-    """Redirect stdout/stderr to devnull while ``enabled`` (reference run_with_diamond.py:18-25)."""
+    """Redirect stdout/stderr to devnull while ``enabled`` (reference run_with_diamond.py:18-25).
+    Re-entrant across threads (concurrent sweep points): the first entrant redirects, the last one
+    out restores."""
+    global _quiet_depth, _quiet_saved
     if not enabled:
         yield
         return
-    with open(os.devnull, "w") as sink, contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+    with _quiet_lock:
+        if _quiet_depth == 0:
+            sink = open(os.devnull, "w")
+            _quiet_saved = (sys.stdout, sys.stderr, sink)
+            sys.stdout = sys.stderr = sink
+        _quiet_depth += 1
+    try:
         yield
+    finally:
+        with _quiet_lock:
+            _quiet_depth -= 1
+            if _quiet_depth == 0:
+                sys.stdout, sys.stderr, sink = _quiet_saved
+                sink.close()
+                _quiet_saved = None
 
 
 def _resolve(path):

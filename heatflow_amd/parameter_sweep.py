@@ -232,10 +232,14 @@ def get_k_values(k0=3.8, half_width=0.5, step=0.02, count=None):
 
 
 def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=False, session_factory=None,
-                    device_id=None, exp_csv=None):
+                    device_id=None, exp_csv=None, concurrent=1):
     """k_sample sweep on one mesh: point i -> rank i mod world; the mesh is broadcast once, each
     rank keeps it resident and only re-values A per point.  Returns rows [{k, rmse, runtime,...}]
-    (rmse of the normalised o-side watcher against the experiment, sweep_test.py:76-93)."""
+    (rmse of the normalised o-side watcher against the experiment, sweep_test.py:76-93).
+
+    ``concurrent`` > 1 runs that many of a rank's points at once, each on its own solver context
+    (own HIP stream, own copy of the mesh): at stock mesh sizes one point cannot fill an MI355X
+    (its kernels are latency-bound), so overlapping points raises the per-GPU throughput."""
     from .analysis_utils import calculate_rmse
 
     rank, world = world_info()
@@ -254,31 +258,57 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
     exp = None
     if exp_csv is not None:
         exp = np.genfromtxt(exp_csv, delimiter=",", names=True)
+    def one_point(k, sess):
+        c = copy.deepcopy(cfg)
+        c["mats"]["p_sample"]["k"] = float(k)
+        outdir = os.path.join(output_dir, f"{k:.2f}")
+        t0 = time.time()
+        row = {"k": float(k), "rmse": float("nan"), "runtime": 0.0, "status": "failed", "error": None, "rank": rank}
+        try:
+            res = run_simulation_impl(stack.kind, c, mesh_folder, False, False, outdir, get_watcher_points(c),
+                                      False, True, session=sess, read_flux=False)
+            row.update(status="success", runtime=time.time() - t0, pcg_iters_mean=float(np.mean(res["iters"])))
+            if exp is not None:
+                ps, os_ = res["watchers"]["pside"], res["watchers"]["oside"]
+                span = ps.max() - ps.min()
+                sim_o = (os_ - os_[0]) / span
+                ic = float(c["heating"]["ic_temp"])
+                exp_o = exp["oside"] - exp["oside"][0] + ic
+                exp_o = (exp_o - exp_o[0]) / (exp["temp"].max() - exp["temp"].min())
+                row["rmse"] = calculate_rmse(exp["time"], exp_o, res["times"], sim_o)
+        except Exception as e:
+            row.update(error=str(e))
+        return row
+
+    mine = [k for _, k in shard(list(k_values), rank, world)]
+    sessions = [session]
     rows = []
     try:
-        for idx, k in shard(list(k_values), rank, world):
-            c = copy.deepcopy(cfg)
-            c["mats"]["p_sample"]["k"] = float(k)
-            outdir = os.path.join(output_dir, f"{k:.2f}")
-            t0 = time.time()
-            row = {"k": float(k), "rmse": float("nan"), "runtime": 0.0, "status": "failed", "error": None, "rank": rank}
-            try:
-                res = run_simulation_impl(stack.kind, c, mesh_folder, False, False, outdir, get_watcher_points(c),
-                                          False, True, session=session)
-                row.update(status="success", runtime=time.time() - t0, pcg_iters_mean=float(np.mean(res["iters"])))
-                if exp is not None:
-                    ps, os_ = res["watchers"]["pside"], res["watchers"]["oside"]
-                    span = ps.max() - ps.min()
-                    sim_o = (os_ - os_[0]) / span
-                    ic = float(c["heating"]["ic_temp"])
-                    exp_o = exp["oside"] - exp["oside"][0] + ic
-                    exp_o = (exp_o - exp_o[0]) / (exp["temp"].max() - exp["temp"].min())
-                    row["rmse"] = calculate_rmse(exp["time"], exp_o, res["times"], sim_o)
-            except Exception as e:
-                row.update(error=str(e))
-            rows.append(row)
+        if concurrent > 1 and len(mine) > 1:
+            import queue
+            from concurrent.futures import ThreadPoolExecutor
+
+            for _ in range(min(concurrent, len(mine)) - 1):
+                sessions.append(session_factory(*arrays, tag_map) if session_factory
+                                else SimulationSession(*arrays, tag_map, device_id=device_id))
+            free = queue.Queue()
+            for sess in sessions:
+                free.put(sess)
+
+            def task(k):
+                sess = free.get()
+                try:
+                    return one_point(k, sess)
+                finally:
+                    free.put(sess)
+
+            with ThreadPoolExecutor(max_workers=len(sessions)) as pool:
+                rows = list(pool.map(task, mine))
+        else:
+            rows = [one_point(k, session) for k in mine]
     finally:
-        session.close()
+        for sess in sessions:
+            sess.close()
     d = _dist()
     if d is not None and world > 1:
         gathered = [None] * world
