@@ -185,6 +185,16 @@ void dev_free(T** p) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
 
+// Scratch device buffer released on every exit path of the function that owns it.
+template <typename T>
+struct DevTemp {
+  T* p = nullptr;
+  ~DevTemp() { dev_free(&p); }
+  DevTemp() = default;
+  DevTemp(const DevTemp&) = delete;
+  DevTemp& operator=(const DevTemp&) = delete;
+};
+
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
@@ -1147,7 +1157,8 @@ int build_amg(hf_ctx* ctx) {
       for (int k = Ac.ptr[i]; k < Ac.ptr[i + 1]; ++k) dense[static_cast<size_t>(i) * nc + Ac.idx[k]] = Ac.val[k];
       eye[static_cast<size_t>(i) * nc + i] = 1.0;
     }
-    double *d_dense = nullptr, *d_inv = nullptr, *d_prow = nullptr, *d_pcol = nullptr;
+    DevTemp<double> t_dense, t_inv, t_prow, t_pcol;
+    double *&d_dense = t_dense.p, *&d_inv = t_inv.p, *&d_prow = t_prow.p, *&d_pcol = t_pcol.p;
     HF_TRY(dev_alloc(ctx, &d_dense, dense.size()));
     HF_TRY(dev_alloc(ctx, &d_inv, eye.size()));
     HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv, static_cast<size_t>(nc) * ld));
@@ -1167,7 +1178,6 @@ int build_amg(hf_ctx* ctx) {
     HF_HIP(hipMemcpy2DAsync(ctx->d_coarse_inv, sizeof(double) * ld, d_inv, sizeof(double) * nc, sizeof(double) * nc, nc,
                             hipMemcpyDeviceToDevice, ctx->stream));
     HF_HIP(hipStreamSynchronize(ctx->stream));
-    dev_free(&d_dense); dev_free(&d_inv); dev_free(&d_prow); dev_free(&d_pcol);
     ctx->coarse_ld = ld;
     ctx->coarse_n = nc;
   }
@@ -1713,7 +1723,8 @@ int hf_flux_setup(hf_ctx* ctx) {
   HF_TRY(dev_alloc(ctx, &ctx->d_bz, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_br, n));
   // M_r(1): the element kernel with rho_c = 1, kappa = 0, dt = 0 (its A output = M goes to scratch)
-  double *d_one = nullptr, *d_zero = nullptr, *d_scratch = nullptr;
+  DevTemp<double> t_one, t_zero, t_scratch;
+  double *&d_one = t_one.p, *&d_zero = t_zero.p, *&d_scratch = t_scratch.p;
   HF_TRY(dev_alloc(ctx, &d_one, ctx->tab_len));
   HF_TRY(dev_alloc(ctx, &d_zero, ctx->tab_len));
   HF_TRY(dev_alloc(ctx, &d_scratch, ctx->nnz));
@@ -1727,7 +1738,6 @@ int hf_flux_setup(hf_ctx* ctx) {
   HF_HIP(hipMemsetAsync(ctx->d_gr, 0, sizeof(double) * n, ctx->stream));
   HF_HIP(hipGetLastError());
   HF_HIP(hipStreamSynchronize(ctx->stream));
-  dev_free(&d_one); dev_free(&d_zero); dev_free(&d_scratch);
   ctx->flux_ready = true;
   ctx->pred_flux[0] = ctx->pred_flux[1] = 0;
   return HF_OK;
@@ -1819,8 +1829,8 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, doubl
   for (int32_t q = 0; q < ns; ++q)
     if (nodes[q] < 0 || nodes[q] >= ctx->n) return fail(ctx, HF_ERR_ARG, "hf_run: node %d outside [0,%d)", nodes[q], ctx->n);
   HF_HIP(hipSetDevice(ctx->dev));
-  double* d_gall = nullptr;
-  double* d_sall = nullptr;
+  DevTemp<double> t_gall, t_sall;
+  double *&d_gall = t_gall.p, *&d_sall = t_sall.p;
   if (ctx->nbc > 0) {
     HF_TRY(dev_alloc(ctx, &d_gall, static_cast<size_t>(n_steps) * ctx->nbc));
     HF_HIP(copy_sync(ctx, d_gall, g_all, sizeof(double) * n_steps * ctx->nbc, hipMemcpyHostToDevice));
@@ -1848,8 +1858,6 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, doubl
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->last_ms = ms;
   if (ns > 0 && rc == HF_OK) (void)copy_sync(ctx, samples, d_sall, sizeof(double) * n_steps * ns, hipMemcpyDeviceToHost);
-  dev_free(&d_gall);
-  dev_free(&d_sall);
   return rc;
 }
 
