@@ -118,3 +118,24 @@ def test_c3_one_million_dof_time_loop_properties(hip, c3):
             prob.close()
     assert np.abs(fields[1] - 300.0).max() > 0.5       # the curve first dips below its start value
     assert np.abs(fields[0] - fields[1]).max() <= 2e-5
+
+
+def test_c3_one_million_dof_first_steps_match_oracle(hip, c3):
+    """The headline configuration against the oracle itself: sparse LU of the 1.04M-DOF operator
+    (a few seconds on the GPU box's host), then the first 10 steps field by field."""
+    cfg, stack, mesh = c3
+    nsteps = 10
+    ref = oracle_run(cfg, mesh, nsteps)
+    prob = make_problem(cfg, stack, mesh, precond=1)
+    try:
+        for bc in prob.bcs:
+            bc.update(0.0)
+        worst = 0.0
+        for k in range(nsteps):
+            prob.step((k + 1) * prob.dt, only=[prob.bcs[3]])
+            worst = max(worst, float(np.abs(prob.state() - ref["fields"][k]).max()))
+        assert worst <= 1e-4, f"{worst:.3e} K"
+        assert np.abs(ref["fields"][-1] - 300.0).max() > 0.5
+        print(f"C3: worst |dT| over {nsteps} steps = {worst:.2e} K, iterations/step = {prob.iters}")
+    finally:
+        prob.close()
