@@ -101,6 +101,11 @@ def cpu_baseline(cfg, mesh, n_sample_steps, first_step):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): everything else - RCCL's version banner, library
+    # chatter - is sent to stderr by pointing fd 1 at fd 2 until the result is written
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
@@ -253,7 +258,7 @@ def main():
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     prob.close()
     if dist is not None:
         dist.destroy_process_group()
