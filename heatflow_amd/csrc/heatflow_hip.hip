@@ -121,6 +121,7 @@ struct hf_ctx {
   double* d_coarse_inv = nullptr;
   int coarse_n = 0, coarse_ld = 0;   // dense inverse, row-major with an even leading dimension (16-byte row loads)
   double amg_opc = 0.0, amg_setup_s = 0.0;
+  long long amg_fallbacks = 0;   // steps finished by Jacobi-PCG after a multigrid-PCG breakdown
   double *d_z = nullptr, *d_z2 = nullptr;
   // read-flux projection (hf_flux_setup): unit-rho_c r-weighted mass matrix and the projected gradient
   bool flux_ready = false;
@@ -1407,7 +1408,17 @@ int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
                        ctx->d_b, ctx->d_u);
   }
   const LinSys sys{ctx->d_A, ctx->d_dinv, ctx->d_u, ctx->d_b};
-  return pcg_solve(ctx, sys, ctx->precond == 1 && ctx->amg_ready, rtol, atol, max_it, &ctx->pred_iters);
+  const bool use_amg = ctx->precond == 1 && ctx->amg_ready;
+  int rc = pcg_solve(ctx, sys, use_amg, rtol, atol, max_it, &ctx->pred_iters);
+  if (rc == HF_ERR_NOCONV && use_amg && ctx->h_scal->done == 2) {
+    // breakdown inside the multigrid-preconditioned loop (p.Ap <= 0: the preconditioner was not SPD for
+    // this operator): finish the step with the Jacobi preconditioner from the current iterate - still on
+    // the GPU - and count the event
+    ctx->amg_fallbacks += 1;
+    int pred = 0;
+    rc = pcg_solve(ctx, sys, false, rtol, atol, max_it, &pred);
+  }
+  return rc;
 }
 
 int ensure_samples(hf_ctx* ctx, int ns) {
@@ -1695,6 +1706,12 @@ int hf_set_precond(hf_ctx* ctx, int32_t kind, int32_t reuse) {
   if (kind == 0) { (void)hipSetDevice(ctx->dev); free_amg(ctx); }
   ctx->precond = kind;
   ctx->amg_reuse = reuse ? 1 : 0;
+  return HF_OK;
+}
+
+int hf_get_amg_fallbacks(hf_ctx* ctx, int64_t* count) {
+  if (!ctx || !count) return HF_ERR_ARG;
+  *count = ctx->amg_fallbacks;
   return HF_OK;
 }
 

@@ -21,7 +21,7 @@ K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS = range(6)
 
 EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_materials",
-    "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_get_amg_info", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
+    "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
     "hf_flux_setup", "hf_flux_project", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
 
@@ -85,6 +85,7 @@ def load_library():
         "hf_assemble": [vp, dbl, i32],
         "hf_set_precond": [vp, i32, i32],
         "hf_get_amg_info": [vp, pi, pi, i32, pd, pd],
+        "hf_get_amg_fallbacks": [vp, C.POINTER(i64)],
         "hf_set_state": [vp, pd],
         "hf_get_state": [vp, pd],
         "hf_sample": [vp, i32, pi, pd],
@@ -200,7 +201,10 @@ class HeatflowHIP:
         nl, opc, secs = C.c_int32(), C.c_double(), C.c_double()
         rows = np.zeros(16, dtype=np.int32)
         self._check(self._lib.hf_get_amg_info(self._ctx, C.byref(nl), _pi(rows), 16, C.byref(opc), C.byref(secs)))
-        return {"levels": nl.value, "rows": rows[:nl.value].tolist(), "op_complexity": opc.value, "setup_s": secs.value}
+        fb = C.c_int64()
+        self._check(self._lib.hf_get_amg_fallbacks(self._ctx, C.byref(fb)))
+        return {"levels": nl.value, "rows": rows[:nl.value].tolist(), "op_complexity": opc.value, "setup_s": secs.value,
+                "jacobi_fallbacks": fb.value}
 
     def assemble(self, dt, mode=ASM_LDS_ATOMIC):
         self._check(self._lib.hf_assemble(self._ctx, float(dt), int(mode)))

@@ -106,6 +106,10 @@ int hf_set_precond(hf_ctx* ctx, int32_t kind, int32_t reuse);
 int hf_get_amg_info(hf_ctx* ctx, int32_t* n_levels, int32_t* level_rows, int32_t max_levels, double* op_complexity,
                     double* setup_seconds);
 
+/* Number of hf_step solves that hit a breakdown (p.Ap <= 0) in the multigrid-preconditioned loop and
+ * were finished with the Jacobi preconditioner instead (still on the GPU).  0 in every case tested. */
+int hf_get_amg_fallbacks(hf_ctx* ctx, int64_t* count);
+
 int hf_set_state(hf_ctx* ctx, const double* u);
 int hf_get_state(hf_ctx* ctx, double* u);
 int hf_sample(hf_ctx* ctx, int32_t n_s, const int32_t* nodes, double* out);
