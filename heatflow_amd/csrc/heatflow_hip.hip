@@ -131,7 +131,8 @@ struct hf_ctx {
   // an even number of iterations (all host-side pointer swaps return to their start after two)
   struct IterGraph { const double* A; const double* dinv; double* x; const double* b; bool amg; int iters; hipGraphExec_t exec; };
   std::vector<IterGraph> graphs;
-  bool use_graph = true;
+  bool use_graph = false;      // opt-in (HEATFLOW_GRAPH=1): on this stack the loop is device-bound, replay measured no gain,
+                               // and rocprofv3 --kernel-trace crashes on long runs of graph replays
   // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
@@ -1510,7 +1511,7 @@ int hf_create(int device_id, hf_ctx** out) {
   if (rc == HF_OK && (hipMemsetAsync(ctx->d_scal, 0, sizeof(Scal), ctx->stream) != hipSuccess ||
                       hipStreamSynchronize(ctx->stream) != hipSuccess))
     rc = fail(ctx, HF_ERR_HIP, "hipMemset failed");
-  if (const char* e = std::getenv("HEATFLOW_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
+  if (const char* e = std::getenv("HEATFLOW_GRAPH")) ctx->use_graph = (e[0] == '1');
   *out = ctx;
   return rc;
 }

@@ -462,3 +462,24 @@ def test_two_contexts_on_two_threads_agree_with_sequential(hip, case_with_diamon
         t.join()
     assert set(par) == {"amg", "jac"}
     assert np.array_equal(par["amg"], seq["amg"]) and np.array_equal(par["jac"], seq["jac"])   # deterministic reductions
+
+
+def test_graph_replay_gives_identical_results(hip, case_with_diamond_small, monkeypatch):
+    """HEATFLOW_GRAPH=1 replays the PCG loops from captured hipGraphs; the numbers must not change."""
+    cfg, stack, mesh = case_with_diamond_small
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HEATFLOW_GRAPH", flag)
+        for pc in (0, 1):
+            prob = make_problem(cfg, stack, mesh, precond=pc, assembly_mode=1)
+            try:
+                for bc in prob.bcs:
+                    bc.update(0.0)
+                for k in range(9):
+                    prob.step((k + 1) * prob.dt)
+                out[(flag, pc)] = (prob.state(), list(prob.iters))
+            finally:
+                prob.close()
+    for pc in (0, 1):
+        assert out[("0", pc)][1] == out[("1", pc)][1]
+        assert np.array_equal(out[("0", pc)][0], out[("1", pc)][0])
