@@ -1,7 +1,7 @@
 // Host-side set-up of a smoothed-aggregation multigrid hierarchy for the SPD operator
 // A_hat = M + dt K (Dirichlet rows = identity).  Plain C++ (no HIP): strength graph,
 // greedy aggregation, Jacobi-smoothed prolongator P = (I - w D^-1 A) T, Galerkin
-// A_c = P^T A P, dense inverse of the coarsest operator.  The V-cycle itself runs on the GPU
+// A_c = P^T A P.  The dense inverse of the coarsest operator and the V-cycle itself run on the GPU
 // (heatflow_hip.hip) with the same CSR SpMV kernels as the PCG loop.
 //
 // This has no counterpart in the reference (it factors with MUMPS, run_with_diamond.py:389-394);
@@ -168,40 +168,6 @@ inline double gershgorin_rho(const Csr& A, const std::vector<double>& d) {  // b
   return rho;
 }
 
-// Dense inverse by Gauss-Jordan with partial pivoting (coarsest level, n <= ~1000).
-inline bool dense_inverse(const Csr& A, std::vector<double>& inv) {
-  const int n = A.nrow;
-  std::vector<double> a(static_cast<size_t>(n) * n, 0.0);
-  inv.assign(static_cast<size_t>(n) * n, 0.0);
-  for (int i = 0; i < n; ++i) {
-    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) a[static_cast<size_t>(i) * n + A.idx[k]] = A.val[k];
-    inv[static_cast<size_t>(i) * n + i] = 1.0;
-  }
-  for (int c = 0; c < n; ++c) {
-    int piv = c;
-    for (int r = c + 1; r < n; ++r)
-      if (std::fabs(a[static_cast<size_t>(r) * n + c]) > std::fabs(a[static_cast<size_t>(piv) * n + c])) piv = r;
-    if (a[static_cast<size_t>(piv) * n + c] == 0.0) return false;
-    if (piv != c)
-      for (int j = 0; j < n; ++j) {
-        std::swap(a[static_cast<size_t>(piv) * n + j], a[static_cast<size_t>(c) * n + j]);
-        std::swap(inv[static_cast<size_t>(piv) * n + j], inv[static_cast<size_t>(c) * n + j]);
-      }
-    const double s = 1.0 / a[static_cast<size_t>(c) * n + c];
-    for (int j = 0; j < n; ++j) { a[static_cast<size_t>(c) * n + j] *= s; inv[static_cast<size_t>(c) * n + j] *= s; }
-    for (int r = 0; r < n; ++r) {
-      if (r == c) continue;
-      const double f = a[static_cast<size_t>(r) * n + c];
-      if (f == 0.0) continue;
-      for (int j = 0; j < n; ++j) {
-        a[static_cast<size_t>(r) * n + j] -= f * a[static_cast<size_t>(c) * n + j];
-        inv[static_cast<size_t>(r) * n + j] -= f * inv[static_cast<size_t>(c) * n + j];
-      }
-    }
-  }
-  return true;
-}
-
 struct Level {
   Csr A;                    // operator of this level (level 0: not stored here, the caller owns it)
   Csr P, R;                 // to / from the next coarser level (empty on the coarsest)
@@ -211,8 +177,7 @@ struct Level {
 
 struct Hierarchy {
   std::vector<Level> levels;          // levels[0].A is left empty (the fine operator lives on the device)
-  std::vector<double> coarse_inv;     // dense inverse of the coarsest A
-  int coarse_n = 0;
+  int coarse_n = 0;                   // rows of the coarsest operator (its dense inverse is formed on the device)
   double op_complexity = 0.0;
 };
 
