@@ -143,7 +143,7 @@ class SimulationSession:
         tag_to_rc = {self.material_tags[m.name]: m.properties["rho_cv"] for m in stack.materials}
         return tag_to_k, tag_to_rc
 
-    def run(self, cfg, stack, watcher_points=None, field_sink=None, read_flux=False):
+    def run(self, cfg, stack, watcher_points=None, field_sink=None, read_flux=False, two_sided=False):
         """One simulation (reference loop run_with_diamond.py:456-504).  Returns a dict with
         ``times``, ``watchers`` {name: array}, ``iters``, timing numbers.  ``read_flux`` adds the
         per-step gradient projection of run_no_diamond.py:543-566 (``flux`` entry of the result)."""
@@ -162,6 +162,14 @@ class SimulationSession:
             RowDirichletBC(V, "x", coord=stack.heated_z, length=abs(stack.r_sample) * 2, center=0.0,
                            value=heat.gaussian),
         ]
+        if two_sided:
+            # EXTENSION without a reference implementation (BASELINE config 4 "konopkova two-sided",
+            # SURVEY 8d C4): a second Gaussian Dirichlet line on the outer face of the o-side coupler,
+            # driven by the CSV's `oside` column with the same offset-to-ic_temp convention.
+            heat_o = HeatingCurve(_resolve(cfg["heating"]["file"]), ic_temp, float(cfg["heating"]["fwhm"]), column="oside")
+            bcs.append(RowDirichletBC(V, "x", coord=stack.heated_z_oside, length=abs(stack.r_sample) * 2, center=0.0,
+                                      value=heat_o.gaussian))
+        varying = bcs[3:]
         tag_to_k, tag_to_rc = self._tables(stack)
         key = (dt, tuple(sorted(tag_to_rc.items())), tuple(int(b.row_dofs.sum()) for b in bcs))
         if self.problem is None or key != self._key:
@@ -204,14 +212,14 @@ class SimulationSession:
         print("Beginning loop...")
         t_loop = time.time()
         if field_sink is None and flux is None:
-            times, samples, iters = prob.run(num_steps, watcher_nodes=nodes, time_varying=[bcs[3]])
+            times, samples, iters = prob.run(num_steps, watcher_nodes=nodes, time_varying=varying)
         else:  # step-wise: every field goes to the sink (visualisation) and / or through the flux projection
             for bc in bcs:
                 bc.update(0.0)
             times, rows, iters = [], [], []
             for step in range(num_steps):
                 t = (step + 1) * dt
-                it, _ = prob.step(t, only=[bcs[3]])
+                it, _ = prob.step(t, only=varying)
                 if flux is not None:
                     _, grad_r = prob.backend.flux_project(self.rtol, 5000, want_z=False)
                     flux.record(t, grad_r)
@@ -339,7 +347,8 @@ class _FieldWriter:
 
 def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_mesh=False, output_folder=None,
                         watcher_points=None, write_xdmf=True, suppress_print=False, *, device_id=0, backend=None,
-                        session=None, rtol=DEFAULT_RTOL, max_it=DEFAULT_MAX_IT, read_flux=True, precond=None):
+                        session=None, rtol=DEFAULT_RTOL, max_it=DEFAULT_MAX_IT, read_flux=True, precond=None,
+                        two_sided=False):
     with suppress_output(suppress_print):
         program_start = time.time()
         stack = stack_with_diamond(cfg) if kind == "with_diamond" else stack_no_diamond(cfg)
@@ -365,7 +374,8 @@ def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_me
         try:
             if sink is not None:
                 sink(0.0, np.full(len(session.coords), float(cfg["heating"]["ic_temp"])))
-            result = session.run(cfg, stack, watcher_points, field_sink=sink, read_flux=read_flux and kind == "no_diamond")
+            result = session.run(cfg, stack, watcher_points, field_sink=sink, read_flux=read_flux and kind == "no_diamond",
+                                 two_sided=two_sided)
         finally:
             if sink is not None:
                 sink.close()

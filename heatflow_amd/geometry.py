@@ -39,6 +39,7 @@ class Stack:
     r_sample: float
     kind: str                         # "with_diamond" | "no_diamond"
     extra: dict = field(default_factory=dict)
+    heated_z_oside: float = 0.0       # extension (two-sided heating): outer face of the o-side coupler
 
     def by_name(self, name):
         for m in self.materials:
@@ -85,8 +86,8 @@ def stack_with_diamond(cfg) -> Stack:
         ("o_coupler", o_coup), ("o_ins", o_ins), ("o_diam", o_diam), ("gasket", gasket), ("g_ins", g_ins),
     ]
     mats = [_material(cfg, n, b) for n, b in boxes]
-    return Stack(mats, [z_lo, z_hi, 0.0, r_max], heated_z=p_coup[0], r_sample=r_sample, kind="with_diamond",
-                 extra={"z_ins_pside": t_pins, "z_coupler": t_coup})
+    return Stack(mats, [z_lo, z_hi, 0.0, r_max], heated_z=p_coup[0], heated_z_oside=o_coup[1], r_sample=r_sample,
+                 kind="with_diamond", extra={"z_ins_pside": t_pins, "z_coupler": t_coup})
 
 
 def stack_no_diamond(cfg) -> Stack:
@@ -117,8 +118,8 @@ def stack_no_diamond(cfg) -> Stack:
 
     boxes = [("p_ins", p_ins), ("p_coupler", p_coup), ("p_sample", sample), ("o_coupler", o_coup), ("o_ins", o_ins)]
     mats = [_material(cfg, n, b) for n, b in boxes]
-    return Stack(mats, [z_lo, z_hi, 0.0, r_sample + r_oins], heated_z=p_coup[0], r_sample=r_sample,
-                 kind="no_diamond", extra={"z_ins_pside": t_pins, "z_coupler": t_coup})
+    return Stack(mats, [z_lo, z_hi, 0.0, r_sample + r_oins], heated_z=p_coup[0], heated_z_oside=o_coup[1],
+                 r_sample=r_sample, kind="no_diamond", extra={"z_ins_pside": t_pins, "z_coupler": t_coup})
 
 
 def build_stack(cfg) -> Stack:

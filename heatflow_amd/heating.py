@@ -13,18 +13,22 @@ import numpy as np
 
 
 class HeatingCurve:
-    def __init__(self, csv_path, ic_temp, fwhm):
+    def __init__(self, csv_path, ic_temp, fwhm, column="temp"):
+        """``column`` = CSV column driving the curve: "temp" (p-side, the reference's only use) or
+        "oside" (extension: the o-side face in a two-sided run)."""
         times, temps = [], []
         with open(csv_path, newline="") as f:
             rd = csv.DictReader(f)
             cols = rd.fieldnames or []
             if "temp" not in cols:
                 raise ValueError(f"Heating CSV file {csv_path} must contain a 'temp' column")
+            if column not in cols:
+                raise ValueError(f"Heating CSV file {csv_path} must contain a '{column}' column")
             if "time" not in cols:
                 raise ValueError(f"Heating CSV file {csv_path} must contain a 'time' column")
             for row in rd:
                 try:
-                    t, T = float(row["time"]), float(row["temp"])
+                    t, T = float(row["time"]), float(row[column])
                 except (TypeError, ValueError):
                     continue
                 if np.isnan(t) or np.isnan(T):

@@ -161,7 +161,7 @@ def locate_row_dofs(coords, location, coord=None, length=None, center=None, widt
     return dofs
 
 
-def read_heating_csv(path):
+def read_heating_csv(path, column="temp"):
     """(time, temp) sorted by time, non-numeric rows dropped (run_with_diamond.py:254-265)."""
     t, T = [], []
     with open(path, newline="") as f:
@@ -172,7 +172,7 @@ def read_heating_csv(path):
             raise ValueError(f"Heating CSV file {path} must contain a 'time' column")
         for row in rd:
             try:
-                a, b = float(row["time"]), float(row["temp"])
+                a, b = float(row["time"]), float(row[column])
             except (TypeError, ValueError):
                 continue
             if np.isnan(a) or np.isnan(b):
@@ -361,6 +361,11 @@ def run_reference_algorithm(cfg, coords, tris, tags, material_tags, heating_csv,
         {"dofs": locate_row_dofs(coords, "x", coord=heated_z, length=abs(r_sample) * 2, center=0.0),
          "value": lambda r, t: gaussian_bc_values(r, t, h_time, h_temp, ic, fwhm)},
     ]
+    if second_line is not None:
+        # extension (no reference implementation): second Gaussian line at z = second_line driven by `oside`
+        o_time, o_temp = read_heating_csv(heating_csv, column="oside")
+        bcs.append({"dofs": locate_row_dofs(coords, "x", coord=second_line, length=abs(r_sample) * 2, center=0.0),
+                    "value": lambda r, t: gaussian_bc_values(r, t, o_time, o_temp, ic, fwhm)})
     sol = OracleSolver(coords, tris, tags, tag_to_k, tag_to_rc, dt, bcs, np.full(len(coords), ic))
     steps = nsteps_cfg if num_steps is None else int(num_steps)
     times, watch, fields = [], [], []

@@ -483,3 +483,33 @@ def test_graph_replay_gives_identical_results(hip, case_with_diamond_small, monk
     for pc in (0, 1):
         assert out[("0", pc)][1] == out[("1", pc)][1]
         assert np.array_equal(out[("0", pc)][0], out[("1", pc)][0])
+
+
+def test_two_sided_heating_extension_matches_oracle(hip, tmp_path):
+    """BASELINE config 4's "two-sided heating" has no reference implementation (cfgs/konopkova.yaml is a
+    stub); the extension (second Gaussian line on the o-side coupler face, `oside` column) is checked
+    against the oracle's restatement of the same extension, together with the read-flux outputs."""
+    import os
+    import yaml
+    import run_no_diamond as run
+    from conftest import HEATING_CSV, load_cfg
+    from heatflow_amd.geometry import build_stack, scale_mesh_sizes
+    from heatflow_amd.mesh import load_mesh_arrays
+    from oracle import heat_oracle as ho
+
+    cfg = scale_mesh_sizes(load_cfg("geballe_no_diamond_read_flux"), 8.0)
+    cfg["timing"]["num_steps"] = 14
+    cfg["timing"]["t_final"] = 14 * 1.5e-7
+    mesh_folder, out = str(tmp_path / "mesh"), str(tmp_path / "out")
+    res = run.run_simulation(cfg, mesh_folder, rebuild_mesh=True, output_folder=out, watcher_points=None,
+                             write_xdmf=True, suppress_print=True, two_sided=True)
+    coords, tris, tags = load_mesh_arrays(os.path.join(mesh_folder, "mesh.msh"))
+    mtags = yaml.safe_load(open(os.path.join(mesh_folder, "mesh_cfg.yaml")))["material_tags"]
+    stack = build_stack(cfg)
+    ref = ho.run_reference_algorithm(cfg, coords, tris, tags, mtags, HEATING_CSV, keep_fields=True,
+                                     second_line=stack.heated_z_oside)
+    fld = np.fromfile(os.path.join(out, "output_fields.f64"), dtype="<f8").reshape(15, len(coords))
+    assert np.abs(fld[1:] - ref["fields"]).max() <= FIELD_TOL_K
+    one_sided = ho.run_reference_algorithm(cfg, coords, tris, tags, mtags, HEATING_CSV, keep_fields=True)
+    assert np.abs(ref["fields"][-1] - one_sided["fields"][-1]).max() > 0.5        # the second line matters
+    assert os.path.isfile(os.path.join(out, "radial_gradient.csv"))
