@@ -139,3 +139,34 @@ def test_c3_one_million_dof_first_steps_match_oracle(hip, c3):
         print(f"C3: worst |dT| over {nsteps} steps = {worst:.2e} K, iterations/step = {prob.iters}")
     finally:
         prob.close()
+
+
+def test_c4_stock_read_flux_matches_oracle(hip, c2):
+    """BASELINE config 4 (geballe_no_diamond_read_flux.yaml: the C2 mesh, 50 steps, gradient
+    projection every step): projected dT/dr on the axis against the oracle's projection."""
+    from conftest import load_cfg
+    from oracle import heat_oracle as ho
+
+    _, stack, mesh = c2
+    cfg = load_cfg("geballe_no_diamond_read_flux")
+    assert int(cfg["timing"]["num_steps"]) == 50
+    nsteps = 12
+    ref = oracle_run(cfg, mesh, nsteps)
+    proj = ho.GradientProjector(mesh.coords, mesh.tris)
+    axis = np.nonzero(np.abs(mesh.coords[:, 1]) <= 1e-12)[0]
+    prob = make_problem(cfg, stack, mesh, precond=1)
+    try:
+        prob.backend.flux_setup()
+        for bc in prob.bcs:
+            bc.update(0.0)
+        for k in range(nsteps):
+            prob.step((k + 1) * prob.dt, only=[prob.bcs[3]])
+            _, gr = prob.backend.flux_project(rtol=1e-11, want_z=False)
+            if k % 4 == 3:
+                g_ref = proj.project(ref["fields"][k])[:, 1]
+                scale = max(np.abs(g_ref).max(), 1.0)
+                assert np.abs(gr - g_ref).max() <= 1e-4 * scale + 1e-3
+                assert np.abs(gr[axis] - g_ref[axis]).max() <= 1e-4 * scale + 1e-3
+        assert scale > 1e6 and prob.backend.last_flux_iters.max() < 100
+    finally:
+        prob.close()
