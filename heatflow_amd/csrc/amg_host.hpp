@@ -185,6 +185,11 @@ struct Params {
   double theta = 0.08;      // strength threshold on level 0, halved per level
   int coarse_size = 2500;   // stop when a level has at most this many rows (dense inverse on the GPU)
   int max_levels = 12;
+  // Smoother damping w = smooth_scale * 4/(3 rho) with rho the Gershgorin bound on lambda_max(D^-1 A).
+  // The bound overestimates lambda_max, so scale 1 under-relaxes; any scale < 1.5 keeps w*lambda_max < 2
+  // (the damped-Jacobi sweep, and with it the V-cycle, stays SPD).  Measured at 1M DOF: 1.0 -> 16, 1.2 -> 14,
+  // 1.4 -> 13.5 PCG iterations per step.  The prolongator keeps the classical 4/(3 rho).
+  double smooth_scale = 1.4;
 };
 
 // Build from the fine operator A0 (moved in; released after the first Galerkin product).
@@ -201,7 +206,7 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
     L.dinv.resize(d.size());
     for (size_t i = 0; i < d.size(); ++i) L.dinv[i] = 1.0 / d[i];
     const double rho = gershgorin_rho(A, d);
-    L.omega = 4.0 / (3.0 * rho);
+    L.omega = prm.smooth_scale * 4.0 / (3.0 * rho);
     const bool last = A.nrow <= prm.coarse_size || lev + 1 >= prm.max_levels;
     if (!last) {
       std::vector<int> agg;
@@ -211,7 +216,7 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
         H.levels.push_back(std::move(L));
         break;
       }
-      L.P = smoothed_prolongator(A, d, agg, na, L.omega);
+      L.P = smoothed_prolongator(A, d, agg, na, 4.0 / (3.0 * rho));
       L.R = transpose(L.P);
       Csr AP = spgemm(A, L.P);
       Csr Ac = spgemm(L.R, AP);

@@ -1125,7 +1125,11 @@ int build_amg(hf_ctx* ctx) {
   A0.val.resize(ctx->nnz);
   HF_HIP(copy_sync(ctx, A0.val.data(), ctx->d_A, sizeof(double) * ctx->nnz, hipMemcpyDeviceToHost));
   amg::Hierarchy H;
-  if (!amg::build(std::move(A0), amg::Params(), H)) return fail(ctx, HF_ERR_STATE, "AMG set-up failed (non-positive diagonal or singular coarse operator)");
+  amg::Params prm;
+  if (const char* e = std::getenv("HEATFLOW_AMG_THETA")) prm.theta = std::atof(e);          // tuning knobs
+  if (const char* e = std::getenv("HEATFLOW_AMG_COARSE")) prm.coarse_size = std::atoi(e);
+  if (const char* e = std::getenv("HEATFLOW_AMG_SMOOTH_SCALE")) prm.smooth_scale = std::atof(e);
+  if (!amg::build(std::move(A0), prm, H)) return fail(ctx, HF_ERR_STATE, "AMG set-up failed (non-positive diagonal or singular coarse operator)");
   const size_t nl = H.levels.size();
   ctx->amg.resize(nl);
   for (size_t l = 0; l < nl; ++l) {
