@@ -1,1483 +1,16 @@
-// libheatflow_hip.so - HIP/CDNA4 (gfx950) implementation of include/heatflow_hip.h.
+// libheatflow_hip.so - HIP/CDNA4 (gfx950) implementation of include/heatflow_hip.h: the C ABI.
 //
 // Hot path of cebarker1000/heatflow re-designed for MI355X:
-//   assembly   per-element P1 kernel (r-weighted axisymmetric mass + stiffness), owner-
-//              computes scatter-add into a CSR slab staged in LDS, streamed out once
-//   time step  b = M u^n (CSR SpMV) -> lifting -> set_bc -> Jacobi-PCG (CSR SpMV with
-//              LDS-staged products, wavefront shuffles + fixed-order block partials,
-//              device-resident scalars, no host round trip inside an iteration)
-// Everything is HBM/L2-bandwidth bound; no MFMA (3x3 locals live in registers).
-// Reference semantics being reproduced: run_with_diamond.py:321-337 (forms), :381-394
-// (assemble once, symmetric Dirichlet elimination, solve), :469-481 (loop body).
-
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "amg_host.hpp"
-#include "heatflow_hip.h"
-
-namespace {
-
-constexpr int RB = 256;        // rows per chunk of the vector kernels
-#ifndef HF_RBA
-#define HF_RBA 256
-#endif
-constexpr int RBA = HF_RBA;    // CSR rows owned by one assembly workgroup (= its thread count); 512 measured 7 % slower
-constexpr int TPB = 256;       // threads per workgroup = 4 wavefronts of 64
-constexpr int NCOL = 32;       // max colours per row block (uint32 mask)
-#ifndef HF_UNROLL
-#define HF_UNROLL 4
-#endif
-constexpr int MAXP = 1024;     // max workgroups per launch = partial-sum slots per array
-constexpr int TS = 512;        // SpMV workgroup: 512 threads = 8 wavefronts own 512 consecutive rows per chunk
-                               // (4 such workgroups per CU = 32 waves/CU; measured 20 % faster than 256x16)
-
-struct Scal {                  // device-resident PCG scalars
-  double tol2;                 // (max(rtol*||D^-1 b||, atol))^2
-  double bn2;                  // ||D^-1 b||^2
-  double zz;                   // ||D^-1 r||^2 of the last iterate
-  int iters;
-  int done;                    // 0 running, 1 converged, 2 breakdown
-  int first;                   // 1 until the first update of a solve: the first direction is p = z (beta = 0)
-};
-
-}  // namespace
-
-struct hf_ctx {
-  int dev = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::string err;
-  double last_ms = 0.0;
-
-  int32_t n = 0, ne = 0, nbc = 0;
-  int64_t nnz = 0;
-  int nchunks = 0, P = 0;      // 256-row chunks and grid of the vector kernels / assembly
-  int nchunks_s = 0, Ps = 0;   // 512-row chunks and grid of the SpMV kernel (Ps <= P partials)
-  int max_chunk_nnz_s = 0;
-  bool have_mesh = false, have_mat = false, assembled = false;
-  double dt = 0.0;
-  int mode = 0;
-
-  // host copies of the pattern (needed to build lifting structures)
-  std::vector<int32_t> h_rowptr, h_colidx;
-  std::vector<char> h_tag_used;
-
-  // device: mesh
-  double2* d_zr = nullptr;
-  int4* d_elem = nullptr;
-  int tab_len = 0;
-  double *d_kappa = nullptr, *d_rhoc = nullptr;
-  // device: pattern + owner lists
-  int32_t *d_rowptr = nullptr, *d_colidx = nullptr;
-  int32_t *d_blk_eptr = nullptr, *d_blk_cptr = nullptr;
-  int2* d_blk_ent = nullptr;     // 3 x int2 per owner-list entry
-  int nblk_a = 0;
-  int max_blk_nnz = 0, ncolors = 0;
-  int64_t elist_len = 0;
-  // device: matrices
-  double *d_M = nullptr, *d_A = nullptr, *d_dinv = nullptr;
-  // device: Dirichlet
-  int32_t* d_bc_dofs = nullptr;
-  double* d_g = nullptr;
-  int32_t nlift_rows = 0, nlift = 0;
-  int32_t *d_lift_rows = nullptr, *d_lift_ptr = nullptr, *d_lift_bc = nullptr, *d_lift_slot = nullptr;
-  double* d_lift_val = nullptr;
-  // device: vectors
-  double *d_u = nullptr, *d_b = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr;
-  double *d_uprev = nullptr, *d_ustart = nullptr;   // u^{n-1} and the buffer of the next start vector (rotated with d_u)
-  bool have_prev = false;
-  int extrapolate = 1;         // start PCG from 2 u^n - u^{n-1} (same answer, fewer iterations)
-  double *d_tmp = nullptr;
-  // device: reductions
-  double *d_part_pAp = nullptr, *d_part_rz = nullptr, *d_part_zz = nullptr, *d_part_bn = nullptr;
-  Scal* d_scal = nullptr;
-  Scal* h_scal = nullptr;      // pinned
-  int32_t* d_samp_idx = nullptr;
-  double* d_samp = nullptr;
-  int samp_cap = 0;
-  int pred_iters = 0;
-  // multigrid preconditioner (hf_set_precond): device hierarchy
-  int precond = 0;             // 0 Jacobi, 1 smoothed-aggregation AMG V(1,1)
-  int amg_reuse = 0;           // 1: keep the coarse levels across hf_assemble calls (kappa sweeps)
-  bool amg_ready = false;
-  struct DevCsr {
-    int nrow = 0, ncol = 0, lanes = 8; int64_t nnz = 0; int32_t *ptr = nullptr, *idx = nullptr; double* val = nullptr;
-    int rpc = 0, nchunks = 0, chunk_nnz = 0;   // LDS-staged (stream) kernel geometry; rpc = 0 -> use the sub-wave kernel
-  };
-  struct DevLevel { DevCsr A, P, R; double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr; double omega = 0; int n = 0; };
-  std::vector<DevLevel> amg;
-  double* d_coarse_inv = nullptr;
-  int coarse_n = 0, coarse_ld = 0;   // dense inverse, row-major with an even leading dimension (16-byte row loads)
-  double amg_opc = 0.0, amg_setup_s = 0.0;
-  long long amg_fallbacks = 0;   // steps finished by Jacobi-PCG after a multigrid-PCG breakdown
-  double *d_z = nullptr, *d_z2 = nullptr;
-  // read-flux projection (hf_flux_setup): unit-rho_c r-weighted mass matrix and the projected gradient
-  bool flux_ready = false;
-  double *d_M1 = nullptr, *d_dinv1 = nullptr, *d_gz = nullptr, *d_gr = nullptr, *d_bz = nullptr, *d_br = nullptr;
-  int pred_flux[2] = {0, 0};
-  // hipGraph replay of the PCG loops: one executable graph per (system, preconditioner), each holding
-  // an even number of iterations (all host-side pointer swaps return to their start after two)
-  struct IterGraph { const double* A; const double* dinv; double* x; const double* b; bool amg; int iters; hipGraphExec_t exec; };
-  std::vector<IterGraph> graphs;
-  bool use_graph = false;      // opt-in (HEATFLOW_GRAPH=1): on this stack the loop is device-bound, replay measured no gain,
-                               // and rocprofv3 --kernel-trace crashes on long runs of graph replays
-  // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
-  bool prof = false;
-  std::vector<hipEvent_t> prof_ev;
-  int prof_used = 0, prof_base = 0;
-  double prof_spmv_ms = 0.0;
-  long long prof_spmv_n = 0;
-};
-
-namespace {
-
-int fail(hf_ctx* c, int code, const char* fmt, ...);
-
-hipError_t copy_sync(hf_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
-  if (bytes == 0) return hipSuccess;
-  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
-  return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
-}
-
-int fail(hf_ctx* c, int code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  if (c) c->err = buf;
-  return code;
-}
-
-#define HF_HIP(call)                                                                          \
-  do {                                                                                        \
-    hipError_t e_ = (call);                                                                   \
-    if (e_ != hipSuccess)                                                                     \
-      return fail(ctx, HF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-
-template <typename T>
-int dev_alloc(hf_ctx* ctx, T** p, size_t count) {
-  if (*p) { (void)hipFree(*p); *p = nullptr; }
-  if (count == 0) count = 1;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
-  if (e != hipSuccess) return fail(ctx, HF_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
-  return HF_OK;
-}
-#define HF_TRY(expr) do { int rc_ = (expr); if (rc_ != HF_OK) return rc_; } while (0)
-
-// Host<->device copy that is complete on return, issued on the context's own stream (never the legacy
-// stream: contexts on other threads may be capturing graphs, which a legacy-stream copy would break).
-hipError_t copy_sync(hf_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
-
-template <typename T>
-void dev_free(T** p) {
-  if (*p) { (void)hipFree(*p); *p = nullptr; }
-}
-
-// Scratch device buffer released on every exit path of the function that owns it.
-template <typename T>
-struct DevTemp {
-  T* p = nullptr;
-  ~DevTemp() { dev_free(&p); }
-  DevTemp() = default;
-  DevTemp(const DevTemp&) = delete;
-  DevTemp& operator=(const DevTemp&) = delete;
-};
-
-// ------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------
-
-// Sum over the 256 threads of a workgroup, identical order every run: 64-lane shuffle tree
-// per wavefront, then the four wave sums added in wave order.  Every thread gets the sum.
-template <int NW = 4>
-__device__ __forceinline__ double block_sum(double v, double* sw) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) sw[w] = v;
-  __syncthreads();
-  double t = sw[0];
-#pragma unroll
-  for (int k = 1; k < NW; ++k) t += sw[k];
-  __syncthreads();
-  return t;
-}
-
-// Fixed-order sum of the P per-workgroup partials written by the previous kernel.
-__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int P, double* s4) {
-  double v = 0.0;
-  for (int k = threadIdx.x; k < P; k += TPB) v += part[k];
-  return block_sum(v, s4);
-}
-
-// Chunk schedule of the row-chunked kernels.  Workgroups are dealt round-robin over the 8 XCDs
-// (blockIdx % 8 says which blocks share an XCD and its L2; speed only, never correctness), so with
-// HF_XCD_MAP each XCD group walks one contiguous eighth of the chunk range: spatially adjacent chunks
-// (Morton order) then share an L2, which keeps the SpMV's neighbour gathers and a chunk's vector
-// slices from kernel to kernel on the same XCD.  Every kernel uses the same schedule.
-#ifndef HF_XCD_MAP
-#define HF_XCD_MAP 1
-#endif
-struct ChunkIter {
-  int chunk, step, end;
-  __device__ __forceinline__ ChunkIter(int nchunks) {
-    if (HF_XCD_MAP && (gridDim.x & 7) == 0) {
-      const int per = (nchunks + 7) >> 3;
-      const int xcd = blockIdx.x & 7;
-      chunk = xcd * per + (blockIdx.x >> 3);
-      step = gridDim.x >> 3;
-      end = min(nchunks, (xcd + 1) * per);
-    } else {
-      chunk = blockIdx.x;
-      step = gridDim.x;
-      end = nchunks;
-    }
-  }
-};
-
-// r-weighted P1 element matrices (reference forms run_with_diamond.py:328-331).
-//   M_ii = rho_c |K| (3 r_i + r_j + r_k)/30,  M_ij = rho_c |K| (2 r_i + 2 r_j + r_k)/60
-//   K_ij = kappa |K| rbar (b_i b_j + c_i c_j)/d^2, d = 2*signed area, rbar = mean r
-// m[] / k[] hold the symmetric 3x3 as {00, 11, 22, 01, 02, 12}.
-__device__ __forceinline__ void element_local(const double2 p0, const double2 p1, const double2 p2, double rho_c,
-                                              double kappa, double m[6], double k[6]) {
-  // No FMA contraction here: the same element is evaluated by different workgroups (and by
-  // different unrolled copies of the caller); every evaluation must give the same bits so that the
-  // assembled matrices stay exactly symmetric.
-#pragma clang fp contract(off)
-  const double d = (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
-  const double area = 0.5 * fabs(d);
-  const double b0 = p1.y - p2.y, b1 = p2.y - p0.y, b2 = p0.y - p1.y;
-  const double c0 = p2.x - p1.x, c1 = p0.x - p2.x, c2 = p1.x - p0.x;
-  const double rsum = (p0.y + p1.y) + p2.y;
-  const double ks = kappa * area * (rsum / 3.0) / (d * d);
-  k[0] = ks * (b0 * b0 + c0 * c0);
-  k[1] = ks * (b1 * b1 + c1 * c1);
-  k[2] = ks * (b2 * b2 + c2 * c2);
-  k[3] = ks * (b0 * b1 + c0 * c1);
-  k[4] = ks * (b0 * b2 + c0 * c2);
-  k[5] = ks * (b1 * b2 + c1 * c2);
-  const double ms = rho_c * area;
-  m[0] = ms * ((2.0 * p0.y + rsum) / 30.0);
-  m[1] = ms * ((2.0 * p1.y + rsum) / 30.0);
-  m[2] = ms * ((2.0 * p2.y + rsum) / 30.0);
-  m[3] = ms * ((rsum + p0.y + p1.y) / 60.0);
-  m[4] = ms * ((rsum + p0.y + p2.y) / 60.0);
-  m[5] = ms * ((rsum + p1.y + p2.y) / 60.0);
-}
-
-__device__ __forceinline__ int sym_index(int a, int b) {  // (a,b) -> slot in {00,11,22,01,02,12}
-  return a == b ? a : (a + b + 2);                        // 01->3, 02->4, 12->5
-}
-
-// ------------------------------------------------------------------------------------------
-// Assembly, LDS-staged owner-computes.  Workgroup `blk` owns rows [blk*RBA, blk*RBA+RBA): it
-// stages that slab of M and A (values) plus its column indices in LDS, walks the elements
-// incident to its rows (precomputed list; an element on a block boundary is visited by each
-// owning block, which adds only the rows it owns), and writes the slab out coalesced.
-//   COLORED = false: LDS f64 atomics (ds_add_f64), any order
-//   COLORED = true : elements grouped by colour (no two share an owned row), plain RMW,
-//                    barrier between colours -> bitwise reproducible
-// ------------------------------------------------------------------------------------------
-// One list entry = 24 bytes = three int2: (n0, n1) (n2, tag<<11 | owned<<8 | off8) (off0..3, off4..7):
-// the element record and the offsets of its nine contributions (a,b) = (0,0) (0,1) ... (2,2) inside
-// the CSR rows of its nodes; `owned` marks the nodes whose rows this workgroup owns.
-struct AsmEntry { int n0, n1, n2; unsigned w3, off03, off47; };
-
-__device__ __forceinline__ AsmEntry load_entry(const int2* __restrict__ ent, int q) {
-  const int2 a = ent[3 * q], b = ent[3 * q + 1], c = ent[3 * q + 2];
-  return AsmEntry{a.x, a.y, b.x, static_cast<unsigned>(b.y), static_cast<unsigned>(c.x), static_cast<unsigned>(c.y)};
-}
-
-template <bool COLORED>
-__global__ __launch_bounds__(RBA) void k_assemble_lds(int n, int cap, const int32_t* __restrict__ rowptr,
-                                                      const int32_t* __restrict__ blk_eptr,
-                                                      const int32_t* __restrict__ blk_cptr,
-                                                      const int2* __restrict__ blk_ent,
-                                                      const double2* __restrict__ zr,
-                                                      const double* __restrict__ kappa_tab,
-                                                      const double* __restrict__ rhoc_tab, double dt,
-                                                      double* __restrict__ Mv, double* __restrict__ Av) {
-  extern __shared__ double smem[];
-  double* sM = smem;
-  double* sA = smem + cap;
-  int* sR = reinterpret_cast<int*>(smem + 2 * cap);
-
-  const int blk = blockIdx.x;
-  const int r0 = blk * RBA;
-  const int r1 = min(n, r0 + RBA);
-  const int k0 = rowptr[r0];
-  const int nk = rowptr[r1] - k0;
-  for (int k = threadIdx.x; k < nk; k += RBA) {
-    sM[k] = 0.0;
-    sA[k] = 0.0;
-  }
-  for (int k = threadIdx.x; k <= r1 - r0; k += RBA) sR[k] = rowptr[r0 + k] - k0;
-  __syncthreads();
-
-  auto scatter = [&](const AsmEntry e, const double2 p0, const double2 p1, const double2 p2) {
-    double m[6], kk[6], av6[6];
-    const int tag = static_cast<int>(e.w3 >> 11);
-    element_local(p0, p1, p2, rhoc_tab[tag], kappa_tab[tag], m, kk);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) av6[q] = fma(dt, kk[q], m[q]);  // once per unique entry, explicit FMA: same bits everywhere
-    const int nd[3] = {e.n0, e.n1, e.n2};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (!((e.w3 >> (8 + a)) & 1u)) continue;
-      const int base = sR[nd[a] - r0];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const int q9 = a * 3 + b;
-        const unsigned off = q9 < 4 ? (e.off03 >> (8 * q9)) & 0xFFu : q9 < 8 ? (e.off47 >> (8 * (q9 - 4))) & 0xFFu : e.w3 & 0xFFu;
-        const int slot = base + static_cast<int>(off);
-        const int q = sym_index(a, b);
-        if (COLORED) {
-          sM[slot] += m[q];
-          sA[slot] += av6[q];
-        } else {
-          atomicAdd(&sM[slot], m[q]);
-          atomicAdd(&sA[slot], av6[q]);
-        }
-      }
-    }
-  };
-  // The list is laid out per workgroup and streamed coalesced; only the coordinates are gathered.
-  // Three elements in flight per lane: all loads are issued before the first scatter.
-  constexpr int NF = 3;
-  auto run_range = [&](int e0, int e1) {
-    for (int k = e0 + threadIdx.x; k < e1; k += NF * RBA) {
-      AsmEntry e[NF];
-      double2 pa[NF], pb[NF], pc[NF];
-#pragma unroll
-      for (int u = 0; u < NF; ++u) e[u] = load_entry(blk_ent, min(k + u * RBA, e1 - 1));
-#pragma unroll
-      for (int u = 0; u < NF; ++u) { pa[u] = zr[e[u].n0]; pb[u] = zr[e[u].n1]; pc[u] = zr[e[u].n2]; }
-#pragma unroll
-      for (int u = 0; u < NF; ++u)
-        if (k + u * RBA < e1) scatter(e[u], pa[u], pb[u], pc[u]);
-    }
-  };
-
-  if (COLORED) {
-    const int32_t* cp = blk_cptr + static_cast<size_t>(blk) * (NCOL + 1);
-    for (int c = 0; c < NCOL; ++c) {
-      const int e0 = cp[c], e1 = cp[c + 1];
-      if (e0 == e1) { if (e1 == cp[NCOL]) break; else continue; }
-      run_range(e0, e1);
-      __syncthreads();
-    }
-  } else {
-    run_range(blk_eptr[blk], blk_eptr[blk + 1]);
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < nk; k += RBA) {
-    Mv[k0 + k] = sM[k];
-    Av[k0 + k] = sA[k];
-  }
-}
-
-// Baseline: one thread per element, f64 atomics into global CSR (values must be zeroed).
-__global__ __launch_bounds__(TPB) void k_assemble_global(int ne, const int32_t* __restrict__ rowptr,
-                                                         const int32_t* __restrict__ colidx,
-                                                         const int4* __restrict__ elem,
-                                                         const double2* __restrict__ zr,
-                                                         const double* __restrict__ kappa_tab,
-                                                         const double* __restrict__ rhoc_tab, double dt,
-                                                         double* __restrict__ Mv, double* __restrict__ Av) {
-  const int e = blockIdx.x * TPB + threadIdx.x;
-  if (e >= ne) return;
-  const int4 el = elem[e];
-  const int nd[3] = {el.x, el.y, el.z};
-  double m[6], kk[6], av6[6];
-  element_local(zr[el.x], zr[el.y], zr[el.z], rhoc_tab[el.w], kappa_tab[el.w], m, kk);
-#pragma unroll
-  for (int q = 0; q < 6; ++q) av6[q] = fma(dt, kk[q], m[q]);
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const int s0 = rowptr[nd[a]], s1 = rowptr[nd[a] + 1];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      int s = s0;
-      while (s < s1 && colidx[s] != nd[b]) ++s;
-      const int q = sym_index(a, b);
-      atomicAdd(&Mv[s], m[q]);
-      atomicAdd(&Av[s], av6[q]);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Read-flux projection (reference run_no_diamond.py:479-489, 544-550): L2 projection of grad T
-// onto vector P1 with the r-weighted mass matrix.  The reference solves one 2n x 2n system; the
-// components decouple into two scalar solves with M_r(1).  This kernel forms both right-hand
-// sides  b_c[i] = sum_e (d_c T)_e * int_e phi_i r dx,  int_e phi_i r = |K| (2 r_i + r_j + r_k)/12,
-// owner-computes like the assembly: a workgroup owns RBA rows and adds the incident elements.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RBA) void k_grad_rhs(int n, const int32_t* __restrict__ blk_eptr,
-                                                  const int2* __restrict__ blk_ent, const double2* __restrict__ zr,
-                                                  const double* __restrict__ u, double* __restrict__ bz,
-                                                  double* __restrict__ br) {
-  __shared__ double sB[2 * RBA];
-  const int blk = blockIdx.x;
-  const int r0 = blk * RBA;
-  const int r1 = min(n, r0 + RBA);
-  for (int k = threadIdx.x; k < 2 * RBA; k += RBA) sB[k] = 0.0;
-  __syncthreads();
-  for (int q = blk_eptr[blk] + threadIdx.x; q < blk_eptr[blk + 1]; q += RBA) {
-#pragma clang fp contract(off)
-    const AsmEntry e = load_entry(blk_ent, q);
-    const double2 p0 = zr[e.n0], p1 = zr[e.n1], p2 = zr[e.n2];
-    const double u0 = u[e.n0], u1 = u[e.n1], u2 = u[e.n2];
-    const double d = (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
-    const double area = 0.5 * fabs(d);
-    // grad phi_i = (b_i, c_i)/d
-    const double gz = (u0 * (p1.y - p2.y) + u1 * (p2.y - p0.y) + u2 * (p0.y - p1.y)) / d;
-    const double gr = (u0 * (p2.x - p1.x) + u1 * (p0.x - p2.x) + u2 * (p1.x - p0.x)) / d;
-    const double rsum = (p0.y + p1.y) + p2.y;
-    const double wgt[3] = {area * (p0.y + rsum) / 12.0, area * (p1.y + rsum) / 12.0, area * (p2.y + rsum) / 12.0};
-    const int nd[3] = {e.n0, e.n1, e.n2};
-    const unsigned owned = (e.w3 >> 8) & 7u;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (!((owned >> a) & 1u)) continue;
-      atomicAdd(&sB[2 * (nd[a] - r0)], gz * wgt[a]);
-      atomicAdd(&sB[2 * (nd[a] - r0) + 1], gr * wgt[a]);
-    }
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < r1 - r0; k += RBA) {
-    bz[r0 + k] = sB[2 * k];
-    br[r0 + k] = sB[2 * k + 1];
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Dirichlet elimination (what dolfinx assemble_matrix(form, bcs) leaves): BC rows and
-// columns zeroed, unit diagonal.  The column entries A[i, j in B] of free rows i are saved
-// first - they are the lifting operator of apply_lifting (run_with_diamond.py:477).
-// ------------------------------------------------------------------------------------------
-__global__ void k_take_lift(int nlift, const int32_t* __restrict__ slot, double* __restrict__ A,
-                            double* __restrict__ val) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nlift) return;
-  val[q] = A[slot[q]];
-  A[slot[q]] = 0.0;
-}
-
-__global__ void k_bc_rows(int nbc, const int32_t* __restrict__ dofs, const int32_t* __restrict__ rowptr,
-                          const int32_t* __restrict__ colidx, double* __restrict__ A) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nbc) return;
-  const int row = dofs[q];
-  for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) A[k] = (colidx[k] == row) ? 1.0 : 0.0;
-}
-
-__global__ void k_dinv(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                       const double* __restrict__ A, double* __restrict__ dinv) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= n) return;
-  double d = 0.0;
-  for (int k = rowptr[row]; k < rowptr[row + 1]; ++k)
-    if (colidx[k] == row) d = A[k];
-  dinv[row] = 1.0 / d;
-}
-
-// b[row] -= sum_q lift_val[q] * g[lift_bc[q]]   (fixed order -> reproducible)
-__global__ void k_lift(int nrows, const int32_t* __restrict__ rows, const int32_t* __restrict__ ptr,
-                       const int32_t* __restrict__ bc, const double* __restrict__ val,
-                       const double* __restrict__ g, double* __restrict__ b) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nrows) return;
-  double s = 0.0;
-  for (int k = ptr[q]; k < ptr[q + 1]; ++k) s += val[k] * g[bc[k]];
-  b[rows[q]] -= s;
-}
-
-// set_bc on the right-hand side and on the PCG start vector (u_B = g)
-__global__ void k_set_bc(int nbc, const int32_t* __restrict__ dofs, const double* __restrict__ g,
-                         double* __restrict__ b, double* __restrict__ u) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nbc) return;
-  b[dofs[q]] = g[q];
-  u[dofs[q]] = g[q];
-}
-
-__global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* __restrict__ u,
-                         double* __restrict__ out) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < ns) out[q] = u[idx[q]];
-}
-
-// ------------------------------------------------------------------------------------------
-// CSR SpMV, LDS-staged ("CSR-stream"): a workgroup takes chunks of RB consecutive rows; all
-// 256 lanes stream the chunk's values and column indices in nnz order (fully coalesced) and
-// park val*x[col] in LDS; then lane t sums the products of row t in column order.  The
-// summation order per row is the CSR order -> bitwise reproducible, no atomics.
-//   MODE 0: y = A x
-//   MODE 1: y = A x and partial sums of x.y             (PCG: Ap, p.Ap)
-//   MODE 2: r = b - A x; p = D^-1 r; partials r.p, p.p, (D^-1 b)^2   (PCG start)
-//   MODE 3: y = b - A x                                              (multigrid residual)
-//   MODE 4: y = x + w D^-1 (b - A x), partials b.y                   (damped-Jacobi sweep, fused r.z)
-//   MODE 5: y = b - A x; p = w D^-1 y; partials (D^-1 y)^2, (D^-1 b)^2   (AMG-PCG start)
-//   MODE 6: y += A x                                                 (multigrid prolongation)
-//   MODE 7: p = w D^-1 b; y = b - A p   (first Jacobi sweep from zero fused with the residual;
-//           the products gather w*dinv[col]*b[col], so p is never read back)
-//   MODE 8: y = A x; p = 2 x - b        (RHS b = M u^n fused with the extrapolated start
-//           2 u^n - u^{n-1} of the next solve; `b` carries u^{n-1})
-//   MODE 9: PCG iteration head (x = z): convergence test, beta, Ap <- A z + beta Ap, p <- z + beta p,
-//           p.Ap partials - SpMV and direction update in one pass
-// The chunk is `rpc` rows (512 for the fine operator; fewer for long-row transfer operators so
-// that a chunk's products fit the 64-KB LDS window).
-// ------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows per chunk, <= TS */,
-                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                              const double* __restrict__ vals, const double* __restrict__ x,
-                                              double* __restrict__ y, Scal* __restrict__ scal,
-                                              double* __restrict__ part0, const double* __restrict__ bvec,
-                                              const double* __restrict__ dinv, double* __restrict__ pvec,
-                                              double* __restrict__ part1, double* __restrict__ part2, double w,
-                                              int npart /* partial slots the consumers sum (>= gridDim.x) */,
-                                              int parity) {
-  extern __shared__ double sprod[];
-  __shared__ double s4[TS / 64];
-  if ((MODE == 1 || MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 9) && scal->done) return;
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-  double beta = 0.0;
-  bool first9 = false;
-  if (MODE == 9) {
-    first9 = scal->first != 0;
-    // PCG iteration head: x = z (preconditioned residual).  Convergence test on the (D^-1 r)^2 partials
-    // of the last update, beta = r.z(new)/r.z(old) from the two parity slots (part1), then in the row
-    // loop  Ap <- A z + beta Ap,  p <- z + beta p  (direction update by recurrence) and p.Ap partials.
-    if (!first9) {
-      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-      for (int k = threadIdx.x; k < npart; k += TS) {
-        v0 += part1[parity * MAXP + k];
-        v1 += part1[(parity ^ 1) * MAXP + k];
-        v2 += part2[k];
-      }
-      const double rz_new = block_sum<TS / 64>(v0, s4);
-      const double rz_old = block_sum<TS / 64>(v1, s4);
-      const double zz = block_sum<TS / 64>(v2, s4);
-      const bool conv = zz <= scal->tol2;
-      if (blockIdx.x == 0 && threadIdx.x == 0) {
-        scal->zz = zz;
-        if (conv) scal->done = 1;
-      }
-      if (conv) return;
-      beta = rz_new / rz_old;
-    }
-  }
-  const ChunkIter sched(nchunks);
-  for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
-    const int r0 = chunk * rpc;
-    const int r1 = min(n, r0 + rpc);
-    const int k0 = rowptr[r0];
-    const int k1 = rowptr[r1];
-    if (MODE != 7) {  // products in nnz order; HF_UNROLL independent value/index loads and gathers in flight per lane
-      int k = k0 + threadIdx.x;
-      for (; k + (HF_UNROLL - 1) * TS < k1; k += HF_UNROLL * TS) {
-        int c[HF_UNROLL];
-        double v[HF_UNROLL], xv[HF_UNROLL];
-#pragma unroll
-        for (int u = 0; u < HF_UNROLL; ++u) { c[u] = colidx[k + u * TS]; v[u] = vals[k + u * TS]; }
-#pragma unroll
-        for (int u = 0; u < HF_UNROLL; ++u) xv[u] = x[c[u]];
-#pragma unroll
-        for (int u = 0; u < HF_UNROLL; ++u) sprod[k - k0 + u * TS] = v[u] * xv[u];
-      }
-      for (; k < k1; k += TS) sprod[k - k0] = vals[k] * x[colidx[k]];
-    }
-    if (MODE == 7) {  // operand is w D^-1 b, formed on the fly
-      for (int k = k0 + threadIdx.x; k < k1; k += TS) {
-        const int c = colidx[k];
-        sprod[k - k0] = vals[k] * (w * dinv[c] * bvec[c]);
-      }
-    }
-    __syncthreads();
-    const int row = r0 + threadIdx.x;
-    if (row < r1) {
-      const int a = rowptr[row] - k0, b = rowptr[row + 1] - k0;
-      double s = 0.0;
-      for (int j = a; j < b; ++j) s += sprod[j];
-      if (MODE == 0) {
-        y[row] = s;
-      } else if (MODE == 1) {
-        y[row] = s;
-        acc0 += x[row] * s;
-      } else if (MODE == 2) {
-        const double bi = bvec[row], di = dinv[row];
-        const double ri = bi - s;
-        const double zi = di * ri;
-        y[row] = ri;
-        pvec[row] = zi;
-        acc0 += ri * zi;
-        acc1 += zi * zi;
-        acc2 += (di * bi) * (di * bi);
-      } else if (MODE == 3) {
-        y[row] = bvec[row] - s;
-      } else if (MODE == 4) {
-        const double bi = bvec[row];
-        const double yi = x[row] + w * dinv[row] * (bi - s);
-        y[row] = yi;
-        acc0 += bi * yi;
-      } else if (MODE == 5) {
-        const double bi = bvec[row], di = dinv[row];
-        const double ri = bi - s;
-        y[row] = ri;
-        pvec[row] = w * di * ri;
-        acc1 += (di * ri) * (di * ri);
-        acc2 += (di * bi) * (di * bi);
-      } else if (MODE == 6) {
-        y[row] += s;
-      } else if (MODE == 7) {
-        const double bi = bvec[row];
-        pvec[row] = w * dinv[row] * bi;
-        y[row] = bi - s;
-      } else if (MODE == 8) {
-        y[row] = s;
-        pvec[row] = 2.0 * x[row] - bvec[row];
-      } else {
-        const double api = first9 ? s : s + beta * y[row];          // first iteration: p = z, Ap = A z
-        const double pi = first9 ? x[row] : x[row] + beta * pvec[row];
-        y[row] = api;
-        pvec[row] = pi;
-        acc0 += pi * api;
-      }
-    }
-    __syncthreads();
-  }
-  // consumers sum `npart` slots in a fixed order; this launch has fewer workgroups, the rest are zeros
-  if (MODE == 1 || MODE == 2 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {
-    const double t0 = block_sum<TS / 64>(acc0, s4);
-    if (threadIdx.x == 0) {
-      part0[blockIdx.x] = t0;
-      for (int q = blockIdx.x + gridDim.x; q < npart; q += gridDim.x) part0[q] = 0.0;
-    }
-  }
-  if (MODE == 2 || MODE == 5) {
-    const double t1 = block_sum<TS / 64>(acc1, s4);
-    const double t2 = block_sum<TS / 64>(acc2, s4);
-    if (threadIdx.x == 0) {
-      part1[blockIdx.x] = t1;
-      part2[blockIdx.x] = t2;
-      for (int q = blockIdx.x + gridDim.x; q < npart; q += gridDim.x) { part1[q] = 0.0; part2[q] = 0.0; }
-    }
-  }
-}
-
-// PCG start: tolerance and convergence of the initial iterate (one workgroup).
-__global__ __launch_bounds__(TPB) void k_pcg_begin(int P, double rtol, double atol, const double* __restrict__ part_zz,
-                                                   const double* __restrict__ part_bn, Scal* __restrict__ scal) {
-  __shared__ double s4[4];
-  const double zz = sum_partials(part_zz, P, s4);
-  const double bn2 = sum_partials(part_bn, P, s4);
-  if (threadIdx.x == 0) {
-    const double tol = fmax(rtol * sqrt(bn2), atol);
-    scal->tol2 = tol * tol;
-    scal->bn2 = bn2;
-    scal->zz = zz;
-    scal->iters = 0;
-    scal->first = 1;
-    scal->done = (zz <= tol * tol) ? 1 : 0;
-  }
-}
-
-// x += alpha p; r -= alpha Ap; z = D^-1 r; partials r.z (into the other parity slot), z.z
-__global__ __launch_bounds__(TPB) void k_pcg_update(int n, int nchunks, int P, int parity, Scal* __restrict__ scal,
-                                                    const double* __restrict__ part_pAp, double* __restrict__ part_rz,
-                                                    double* __restrict__ part_zz, double* __restrict__ x,
-                                                    double* __restrict__ r, const double* __restrict__ p,
-                                                    const double* __restrict__ Ap, const double* __restrict__ dinv,
-                                                    double* __restrict__ z) {
-  __shared__ double s4[4];
-  if (scal->done) return;
-  const double pAp = sum_partials(part_pAp, P, s4);
-  const double rz = sum_partials(part_rz + parity * MAXP, P, s4);
-  if (!(pAp > 0.0)) {                                   // breakdown (A_hat is SPD, so only on NaN/garbage)
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal->done = 2;
-    return;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { scal->iters += 1; scal->first = 0; }
-  const double alpha = rz / pAp;
-  double a_rz = 0.0, a_zz = 0.0;
-  const ChunkIter sched(nchunks);
-  for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
-    const int i = chunk * RB + threadIdx.x;
-    if (i < n) {
-      const double ri = r[i] - alpha * Ap[i];
-      const double zi = dinv[i] * ri;
-      x[i] += alpha * p[i];
-      r[i] = ri;
-      z[i] = zi;
-      a_rz += ri * zi;
-      a_zz += zi * zi;
-    }
-  }
-  const double t0 = block_sum(a_rz, s4);
-  const double t1 = block_sum(a_zz, s4);
-  if (threadIdx.x == 0) {
-    part_rz[(parity ^ 1) * MAXP + blockIdx.x] = t0;
-    part_zz[blockIdx.x] = t1;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Generic CSR SpMV for the multigrid transfer operators and coarse levels: LANES lanes of a
-// wavefront share one row (4..64 by the average row length), fixed-order shuffle reduction.
-//   VMODE 0: y = A x      1: y += A x      2: y = b - A x      3: y = x + w D^-1 (b - A x)
-//   VMODE 4: xs = w D^-1 b (stored to xout), y = b - A xs
-// ------------------------------------------------------------------------------------------
-template <int LANES, int VMODE>
-__global__ __launch_bounds__(TPB) void k_spmv_vec(int nrow, const int32_t* __restrict__ ptr,
-                                                  const int32_t* __restrict__ idx, const double* __restrict__ val,
-                                                  const double* __restrict__ x, double* __restrict__ y,
-                                                  const double* __restrict__ b, const double* __restrict__ dinv,
-                                                  double w, const Scal* __restrict__ scal, double* __restrict__ xout) {
-  if (scal->done) return;
-  const int lane = threadIdx.x % LANES;
-  const int rows_per_pass = (gridDim.x * TPB) / LANES;
-  for (int row = (blockIdx.x * TPB + threadIdx.x) / LANES; row < nrow; row += rows_per_pass) {
-    double s = 0.0;
-    const int k1 = ptr[row + 1];
-    if (VMODE == 4) {
-      for (int k = ptr[row] + lane; k < k1; k += LANES) { const int c = idx[k]; s += val[k] * (w * dinv[c] * b[c]); }
-    } else {
-      for (int k = ptr[row] + lane; k < k1; k += LANES) s += val[k] * x[idx[k]];
-    }
-#pragma unroll
-    for (int o = LANES / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LANES);
-    if (lane == 0) {
-      if (VMODE == 0) y[row] = s;
-      else if (VMODE == 1) y[row] += s;
-      else if (VMODE == 2) y[row] = b[row] - s;
-      else if (VMODE == 3) y[row] = x[row] + w * dinv[row] * (b[row] - s);
-      else { const double bi = b[row]; xout[row] = w * dinv[row] * bi; y[row] = bi - s; }
-    }
-  }
-}
-
-// x = w D^-1 b  (first damped-Jacobi sweep from a zero guess)
-__global__ __launch_bounds__(TPB) void k_scale(int n, double w, const double* __restrict__ dinv,
-                                               const double* __restrict__ b, double* __restrict__ x,
-                                               const Scal* __restrict__ scal) {
-  if (scal->done) return;
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) x[i] = w * dinv[i] * b[i];
-}
-
-// x = Ainv b with the dense inverse of the coarsest operator (row-major, leading dimension ld, even):
-// two wavefronts per row, 16-byte loads, halves combined through LDS.
-__global__ __launch_bounds__(TPB) void k_dense_mv(int n, int ld, const double* __restrict__ Ainv,
-                                                  const double* __restrict__ b, double* __restrict__ x,
-                                                  const Scal* __restrict__ scal) {
-  __shared__ double half_sum[4];
-  if (scal->done) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;            // 0..3: waves 0,1 -> row 2*blk, waves 2,3 -> row 2*blk + 1
-  const int npair = (n + 1) >> 1;
-  for (int pr = blockIdx.x; pr < npair; pr += gridDim.x) {
-    const int row = 2 * pr + (wave >> 1);
-    double s = 0.0;
-    if (row < n) {
-      const double2* arow = reinterpret_cast<const double2*>(Ainv + static_cast<size_t>(row) * ld);
-      const double2* bv = reinterpret_cast<const double2*>(b);
-      const int nv = ld >> 1;
-      for (int j = (wave & 1) * 64 + lane; j < nv; j += 128) {
-        const double2 a = arow[j];
-        const double2 v = bv[j];
-        s += a.x * v.x + a.y * v.y;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (lane == 0) half_sum[wave] = s;
-    __syncthreads();
-    if (lane == 0 && (wave & 1) == 0 && row < n) x[row] = half_sum[wave] + half_sum[wave + 1];
-    __syncthreads();
-  }
-}
-
-// Dense inverse of the coarsest operator on the GPU: Gauss-Jordan without pivoting (the operator
-// is SPD, its pivots stay positive).  Two launches per pivot; A is overwritten by the identity.
-__global__ __launch_bounds__(TPB) void k_gj_pivot(int n, int c, const double* __restrict__ A,
-                                                  const double* __restrict__ Inv, double* __restrict__ prow,
-                                                  double* __restrict__ pcol) {
-  const double piv = A[static_cast<size_t>(c) * n + c];
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) {
-    prow[j] = A[static_cast<size_t>(c) * n + j] / piv;
-    prow[n + j] = Inv[static_cast<size_t>(c) * n + j] / piv;
-    pcol[j] = A[static_cast<size_t>(j) * n + c];
-  }
-}
-
-__global__ __launch_bounds__(TPB) void k_gj_elim(int n, int c, double* __restrict__ A, double* __restrict__ Inv,
-                                                 const double* __restrict__ prow, const double* __restrict__ pcol) {
-  const size_t total = static_cast<size_t>(n) * n;
-  for (size_t q = static_cast<size_t>(blockIdx.x) * TPB + threadIdx.x; q < total; q += static_cast<size_t>(gridDim.x) * TPB) {
-    const int r = static_cast<int>(q / n), j = static_cast<int>(q % n);
-    if (r == c) {
-      A[q] = prow[j];
-      Inv[q] = prow[n + j];
-    } else {
-      const double f = pcol[r];
-      A[q] -= f * prow[j];
-      Inv[q] -= f * prow[n + j];
-    }
-  }
-}
-
-// AMG-PCG: x += alpha p; r -= alpha Ap; z0 = w D^-1 r (pre-smoothed start of the V-cycle);
-// partial (D^-1 r)^2 for the convergence test.  r.z comes from the V-cycle's last kernel.
-__global__ __launch_bounds__(TPB) void k_pcg_update_amg(int n, int nchunks, int P, int parity, Scal* __restrict__ scal,
-                                                        const double* __restrict__ part_pAp,
-                                                        const double* __restrict__ part_rz, double* __restrict__ part_zz,
-                                                        double* __restrict__ x, double* __restrict__ r,
-                                                        const double* __restrict__ p, const double* __restrict__ Ap,
-                                                        const double* __restrict__ dinv, double w, double* __restrict__ z0) {
-  __shared__ double s4[4];
-  if (scal->done) return;
-  const double pAp = sum_partials(part_pAp, P, s4);
-  const double rz = sum_partials(part_rz + parity * MAXP, P, s4);
-  if (!(pAp > 0.0)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal->done = 2;
-    return;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { scal->iters += 1; scal->first = 0; }
-  const double alpha = rz / pAp;
-  double a_zz = 0.0;
-  const ChunkIter sched(nchunks);
-  for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
-    const int i = chunk * RB + threadIdx.x;
-    if (i < n) {
-      const double ri = r[i] - alpha * Ap[i];
-      const double zi = dinv[i] * ri;
-      x[i] += alpha * p[i];
-      r[i] = ri;
-      z0[i] = w * zi;
-      a_zz += zi * zi;
-    }
-  }
-  const double t1 = block_sum(a_zz, s4);
-  if (threadIdx.x == 0) part_zz[blockIdx.x] = t1;
-}
-
-
-// ------------------------------------------------------------------------------------------
-// host side: sparsity pattern, owner lists, colouring
-// ------------------------------------------------------------------------------------------
-struct Pattern {
-  std::vector<int32_t> rowptr, colidx, blk_eptr, blk_cptr, blk_elist;
-  std::vector<int2> blk_ent;       // 3 x int2 per list entry: element record + nine slot offsets + ownership mask
-  int max_blk_nnz = 0, ncolors = 0;
-};
-
-int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const int32_t* tag, Pattern& P) {
-  std::vector<int32_t> nptr(static_cast<size_t>(n) + 1, 0);
-  for (int64_t k = 0; k < 3LL * ne; ++k) nptr[tri[k] + 1]++;
-  for (int32_t i = 0; i < n; ++i) nptr[i + 1] += nptr[i];
-  std::vector<int32_t> nlist(static_cast<size_t>(3) * ne);
-  {
-    std::vector<int32_t> cur(nptr.begin(), nptr.end() - 1);
-    for (int32_t e = 0; e < ne; ++e)
-      for (int a = 0; a < 3; ++a) nlist[cur[tri[3 * e + a]]++] = e;
-  }
-  P.rowptr.assign(static_cast<size_t>(n) + 1, 0);
-  P.colidx.clear();
-  P.colidx.reserve(static_cast<size_t>(8) * n);
-  std::vector<int32_t> tmp;
-  for (int32_t i = 0; i < n; ++i) {
-    tmp.clear();
-    for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
-      const int32_t e = nlist[q];
-      tmp.push_back(tri[3 * e]); tmp.push_back(tri[3 * e + 1]); tmp.push_back(tri[3 * e + 2]);
-    }
-    if (tmp.empty()) return fail(ctx, HF_ERR_ARG, "node %d belongs to no triangle", i);
-    std::sort(tmp.begin(), tmp.end());
-    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-    P.colidx.insert(P.colidx.end(), tmp.begin(), tmp.end());
-    if (P.colidx.size() > static_cast<size_t>(INT32_MAX)) return fail(ctx, HF_ERR_ARG, "nnz exceeds int32");
-    P.rowptr[i + 1] = static_cast<int32_t>(P.colidx.size());
-  }
-  // owner lists + greedy colouring per row block
-  const int nblk = (n + RBA - 1) / RBA;
-  P.blk_eptr.assign(static_cast<size_t>(nblk) + 1, 0);
-  P.blk_cptr.assign(static_cast<size_t>(nblk) * (NCOL + 1), 0);
-  P.blk_elist.clear();
-  P.blk_elist.reserve(static_cast<size_t>(ne) * 3 / 2);
-  std::vector<int32_t> stamp(ne, -1), list, color;
-  std::vector<uint32_t> mask(RBA);
-  P.max_blk_nnz = 0;
-  P.ncolors = 0;
-  for (int b = 0; b < nblk; ++b) {
-    const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
-    P.max_blk_nnz = std::max(P.max_blk_nnz, P.rowptr[r1] - P.rowptr[r0]);
-    list.clear();
-    for (int32_t i = r0; i < r1; ++i)
-      for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
-        const int32_t e = nlist[q];
-        if (stamp[e] != b) { stamp[e] = b; list.push_back(e); }
-      }
-    std::sort(list.begin(), list.end());
-    std::fill(mask.begin(), mask.end(), 0u);
-    color.resize(list.size());
-    int counts[NCOL] = {0};
-    for (size_t k = 0; k < list.size(); ++k) {
-      const int32_t e = list[k];
-      uint32_t used = 0;
-      for (int a = 0; a < 3; ++a) {
-        const int32_t v = tri[3 * e + a];
-        if (v >= r0 && v < r1) used |= mask[v - r0];
-      }
-      if (used == 0xFFFFFFFFu) return fail(ctx, HF_ERR_ARG, "more than %d elements share a node", NCOL);
-      const int c = __builtin_ctz(~used);
-      color[k] = c;
-      counts[c]++;
-      P.ncolors = std::max(P.ncolors, c + 1);
-      for (int a = 0; a < 3; ++a) {
-        const int32_t v = tri[3 * e + a];
-        if (v >= r0 && v < r1) mask[v - r0] |= (1u << c);
-      }
-    }
-    const int32_t base = static_cast<int32_t>(P.blk_elist.size());
-    int32_t* cp = &P.blk_cptr[static_cast<size_t>(b) * (NCOL + 1)];
-    cp[0] = base;
-    for (int c = 0; c < NCOL; ++c) cp[c + 1] = cp[c] + counts[c];
-    P.blk_elist.resize(P.blk_elist.size() + list.size());
-    int32_t cur[NCOL];
-    for (int c = 0; c < NCOL; ++c) cur[c] = cp[c];
-    for (size_t k = 0; k < list.size(); ++k) P.blk_elist[cur[color[k]]++] = list[k];
-    P.blk_eptr[b] = base;
-    P.blk_eptr[b + 1] = static_cast<int32_t>(P.blk_elist.size());
-  }
-  // widen every list entry with the offsets of its nine contributions inside the CSR rows
-  P.blk_ent.resize(3 * P.blk_elist.size());
-  for (int b = 0; b < nblk; ++b) {
-    const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
-    for (int32_t q = P.blk_eptr[b]; q < P.blk_eptr[b + 1]; ++q) {
-      const int32_t e = P.blk_elist[q];
-      const int32_t nd[3] = {tri[3 * e], tri[3 * e + 1], tri[3 * e + 2]};
-      uint32_t pos[9] = {0}, owned = 0;
-      for (int a = 0; a < 3; ++a) {
-        if (nd[a] < r0 || nd[a] >= r1) continue;
-        owned |= 1u << a;
-        const int32_t* rb = &P.colidx[P.rowptr[nd[a]]];
-        const int32_t* re = &P.colidx[P.rowptr[nd[a] + 1]];
-        if (re - rb > 255) return fail(ctx, HF_ERR_ARG, "row %d holds more than 255 entries", nd[a]);
-        for (int c = 0; c < 3; ++c) pos[a * 3 + c] = static_cast<uint32_t>(std::lower_bound(rb, re, nd[c]) - rb);
-      }
-      if (tag[e] >= (1 << 21)) return fail(ctx, HF_ERR_ARG, "cell tag %d does not fit the packed list entry (max 2^21 - 1)", tag[e]);
-      const uint32_t w3 = pos[8] | (owned << 8) | (static_cast<uint32_t>(tag[e]) << 11);
-      P.blk_ent[3 * q] = make_int2(nd[0], nd[1]);
-      P.blk_ent[3 * q + 1] = make_int2(nd[2], static_cast<int>(w3));
-      P.blk_ent[3 * q + 2] = make_int2(static_cast<int>(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24)),
-                                       static_cast<int>(pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24)));
-    }
-  }
-  return HF_OK;
-}
-
-size_t spmv_smem_bytes(const hf_ctx* c) { return static_cast<size_t>(c->max_chunk_nnz_s) * 8; }
-
-// LDS-staged element kernel into (Mout, Aout) with the given coefficient tables.
-int launch_assemble_lds(hf_ctx* ctx, bool colored, const double* kappa_tab, const double* rhoc_tab, double dt,
-                        double* Mout, double* Aout) {
-  const int cap = (ctx->max_blk_nnz + 1) & ~1;  // keep the int array 8-byte aligned
-  const size_t sm = static_cast<size_t>(cap) * 16 + (RBA + 1) * 4;
-  if (sm > 64 * 1024) {  // beyond the default dynamic-LDS window: opt in (160 KB per CU on gfx950)
-    HF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_lds<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sm)));
-    HF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_lds<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sm)));
-  }
-  if (colored)
-    hipLaunchKernelGGL(k_assemble_lds<true>, dim3(ctx->nblk_a), dim3(RBA), sm, ctx->stream, ctx->n, cap, ctx->d_rowptr,
-                       ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_zr, kappa_tab, rhoc_tab, dt, Mout, Aout);
-  else
-    hipLaunchKernelGGL(k_assemble_lds<false>, dim3(ctx->nblk_a), dim3(RBA), sm, ctx->stream, ctx->n, cap, ctx->d_rowptr,
-                       ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_zr, kappa_tab, rhoc_tab, dt, Mout, Aout);
-  HF_HIP(hipGetLastError());
-  return HF_OK;
-}
-
-int launch_assemble(hf_ctx* ctx) {
-  if (ctx->mode == HF_ASM_LDS_COLORED || ctx->mode == HF_ASM_LDS_ATOMIC) {
-    return launch_assemble_lds(ctx, ctx->mode == HF_ASM_LDS_COLORED, ctx->d_kappa, ctx->d_rhoc, ctx->dt, ctx->d_M, ctx->d_A);
-  } else {
-    HF_HIP(hipMemsetAsync(ctx->d_M, 0, sizeof(double) * ctx->nnz, ctx->stream));
-    HF_HIP(hipMemsetAsync(ctx->d_A, 0, sizeof(double) * ctx->nnz, ctx->stream));
-    hipLaunchKernelGGL(k_assemble_global, dim3((ctx->ne + TPB - 1) / TPB), dim3(TPB), 0, ctx->stream, ctx->ne,
-                       ctx->d_rowptr, ctx->d_colidx, ctx->d_elem, ctx->d_zr, ctx->d_kappa, ctx->d_rhoc, ctx->dt,
-                       ctx->d_M, ctx->d_A);
-  }
-  HF_HIP(hipGetLastError());
-  return HF_OK;
-}
-
-template <int MODE>
-void launch_spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr,
-                 const double* bvec = nullptr, double* pvec = nullptr, double* part1 = nullptr,
-                 double* part2 = nullptr, double w = 0.0, const double* dinv = nullptr, hipEvent_t ev_start = nullptr,
-                 hipEvent_t ev_stop = nullptr, int parity = 0) {
-  // With events: the launch carries them (hipExtLaunchKernelGGL), so they bracket the kernel's own
-  // execution on the device - the same interval rocprofv3 reports - not the launch gap before it.
-  if (ev_start != nullptr)
-    hipExtLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), static_cast<std::uint32_t>(spmv_smem_bytes(c)), c->stream,
-                          ev_start, ev_stop, 0u, c->n, c->nchunks_s, static_cast<int>(TS),
-                          static_cast<const int32_t*>(c->d_rowptr), static_cast<const int32_t*>(c->d_colidx), vals, x, y,
-                          c->d_scal, part0, bvec, dinv ? dinv : static_cast<const double*>(c->d_dinv),
-                          pvec, part1, part2, w, c->P, parity);
-  else
-    hipLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), spmv_smem_bytes(c), c->stream, c->n, c->nchunks_s, TS,
-                       c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, dinv ? dinv : c->d_dinv, pvec, part1,
-                       part2, w, c->P, parity);
-}
-
-constexpr int PROF_PAIRS = 64;
-
-// A linear system on the context's sparsity pattern: values, inverse diagonal, unknown, right-hand side.
-struct LinSys { const double* A; const double* dinv; double* x; const double* b; };
-
-// One Jacobi-PCG iteration = 2 kernels: [convergence, beta, Ap/p by recurrence, p.Ap] + [alpha, x, r, z, r.z, z.z]
-void launch_pcg_iteration(hf_ctx* c, const LinSys& s, int parity) {
-  const bool timed = c->prof && c->prof_used < PROF_PAIRS;
-  hipEvent_t e0 = timed ? c->prof_ev[2 * c->prof_used] : nullptr, e1 = timed ? c->prof_ev[2 * c->prof_used + 1] : nullptr;
-  launch_spmv<9>(c, s.A, c->d_z, c->d_Ap, c->d_part_pAp, nullptr, c->d_p, c->d_part_rz, c->d_part_zz, 0.0, nullptr, e0, e1,
-                 parity);
-  if (timed) c->prof_used++;
-  hipLaunchKernelGGL(k_pcg_update, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
-                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, s.x, c->d_r, c->d_p, c->d_Ap, s.dinv, c->d_z);
-}
-
-// ------------------------------------------------------------------------------------------
-// multigrid: hierarchy upload, V-cycle, AMG-PCG step
-// ------------------------------------------------------------------------------------------
-using DevCsr = hf_ctx::DevCsr;
-using DevLevel = hf_ctx::DevLevel;
-
-void free_dev_csr(DevCsr& m) { dev_free(&m.ptr); dev_free(&m.idx); dev_free(&m.val); m = DevCsr(); }
-
-void drop_graphs(hf_ctx* ctx);
-
-void free_amg(hf_ctx* ctx) {
-  drop_graphs(ctx);
-  for (size_t l = 0; l < ctx->amg.size(); ++l) {
-    DevLevel& L = ctx->amg[l];
-    if (l > 0) { free_dev_csr(L.A); dev_free(&L.dinv); dev_free(&L.x); dev_free(&L.b); }
-    free_dev_csr(L.P); free_dev_csr(L.R);
-    dev_free(&L.x2); dev_free(&L.r);
-  }
-  ctx->amg.clear();
-  dev_free(&ctx->d_coarse_inv);
-  ctx->coarse_n = 0;
-  ctx->amg_ready = false;
-}
-
-int lanes_for(const amg::Csr& m) {
-  const double avg = m.nrow ? static_cast<double>(m.nnz()) / m.nrow : 1.0;
-  return avg <= 4.5 ? 4 : avg <= 9.0 ? 8 : avg <= 18.0 ? 16 : avg <= 36.0 ? 32 : 64;
-}
-
-int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d) {
-  d.nrow = h.nrow; d.ncol = h.ncol; d.nnz = h.nnz(); d.lanes = lanes_for(h);
-  d.rpc = 0;
-  if (h.nrow >= 100000) {  // enough 512-row chunks to fill the chip: LDS-staged kernel, chunk products within 64 KB
-    for (int rpc = TS; rpc >= 32; rpc /= 2) {
-      int mx = 0;
-      for (int r0 = 0; r0 < h.nrow; r0 += rpc) mx = std::max(mx, h.ptr[std::min(h.nrow, r0 + rpc)] - h.ptr[r0]);
-      if (mx <= 8000) { d.rpc = rpc; d.nchunks = (h.nrow + rpc - 1) / rpc; d.chunk_nnz = mx; break; }
-    }
-  }
-  HF_TRY(dev_alloc(ctx, &d.ptr, h.ptr.size()));
-  HF_TRY(dev_alloc(ctx, &d.idx, h.idx.size()));
-  HF_TRY(dev_alloc(ctx, &d.val, h.val.size()));
-  HF_HIP(copy_sync(ctx, d.ptr, h.ptr.data(), sizeof(int32_t) * h.ptr.size(), hipMemcpyHostToDevice));
-  if (!h.idx.empty()) {
-    HF_HIP(copy_sync(ctx, d.idx, h.idx.data(), sizeof(int32_t) * h.idx.size(), hipMemcpyHostToDevice));
-    HF_HIP(copy_sync(ctx, d.val, h.val.data(), sizeof(double) * h.val.size(), hipMemcpyHostToDevice));
-  }
-  return HF_OK;
-}
-
-// Build the hierarchy from the assembled, eliminated fine operator (download -> host set-up -> upload).
-int build_amg(hf_ctx* ctx) {
-  const auto t0 = std::chrono::steady_clock::now();
-  free_amg(ctx);
-  amg::Csr A0;
-  A0.nrow = A0.ncol = ctx->n;
-  A0.ptr.assign(ctx->h_rowptr.begin(), ctx->h_rowptr.end());
-  A0.idx.assign(ctx->h_colidx.begin(), ctx->h_colidx.end());
-  A0.val.resize(ctx->nnz);
-  HF_HIP(copy_sync(ctx, A0.val.data(), ctx->d_A, sizeof(double) * ctx->nnz, hipMemcpyDeviceToHost));
-  amg::Hierarchy H;
-  amg::Params prm;
-  if (const char* e = std::getenv("HEATFLOW_AMG_THETA")) prm.theta = std::atof(e);          // tuning knobs
-  if (const char* e = std::getenv("HEATFLOW_AMG_COARSE")) prm.coarse_size = std::atoi(e);
-  if (const char* e = std::getenv("HEATFLOW_AMG_SMOOTH_SCALE")) prm.smooth_scale = std::atof(e);
-  if (!amg::build(std::move(A0), prm, H)) return fail(ctx, HF_ERR_STATE, "AMG set-up failed (non-positive diagonal or singular coarse operator)");
-  const size_t nl = H.levels.size();
-  ctx->amg.resize(nl);
-  for (size_t l = 0; l < nl; ++l) {
-    DevLevel& L = ctx->amg[l];
-    const amg::Level& hl = H.levels[l];
-    L.n = static_cast<int>(hl.dinv.size());
-    L.omega = hl.omega;
-    if (l == 0) {
-      L.A.nrow = L.A.ncol = ctx->n; L.A.nnz = ctx->nnz; L.A.ptr = ctx->d_rowptr; L.A.idx = ctx->d_colidx; L.A.val = ctx->d_A;
-      L.dinv = ctx->d_dinv;
-    } else {
-      HF_TRY(upload_csr(ctx, hl.A, L.A));
-      HF_TRY(dev_alloc(ctx, &L.dinv, L.n));
-      HF_HIP(copy_sync(ctx, L.dinv, hl.dinv.data(), sizeof(double) * L.n, hipMemcpyHostToDevice));
-      HF_TRY(dev_alloc(ctx, &L.x, L.n + 2));
-      HF_TRY(dev_alloc(ctx, &L.b, L.n + 2));
-      HF_TRY(dev_alloc(ctx, &L.x2, L.n + 2));
-      HF_TRY(dev_alloc(ctx, &L.r, L.n + 2));
-      HF_HIP(hipMemsetAsync(L.b, 0, sizeof(double) * (L.n + 2), ctx->stream));   // the dense solve reads b in pairs
-    }
-    if (l + 1 < nl) { HF_TRY(upload_csr(ctx, hl.P, L.P)); HF_TRY(upload_csr(ctx, hl.R, L.R)); }
-  }
-  // coarsest level: dense inverse by Gauss-Jordan on the device
-  ctx->coarse_n = 0;
-  if (nl > 1 && H.coarse_n > 0 && H.coarse_n <= 4096) {
-    const int nc = H.coarse_n;
-    const int ld = (nc + 1) & ~1;
-    const amg::Csr& Ac = H.levels.back().A;
-    std::vector<double> dense(static_cast<size_t>(nc) * nc, 0.0), eye(static_cast<size_t>(nc) * nc, 0.0);
-    for (int i = 0; i < nc; ++i) {
-      for (int k = Ac.ptr[i]; k < Ac.ptr[i + 1]; ++k) dense[static_cast<size_t>(i) * nc + Ac.idx[k]] = Ac.val[k];
-      eye[static_cast<size_t>(i) * nc + i] = 1.0;
-    }
-    DevTemp<double> t_dense, t_inv, t_prow, t_pcol;
-    double *&d_dense = t_dense.p, *&d_inv = t_inv.p, *&d_prow = t_prow.p, *&d_pcol = t_pcol.p;
-    HF_TRY(dev_alloc(ctx, &d_dense, dense.size()));
-    HF_TRY(dev_alloc(ctx, &d_inv, eye.size()));
-    HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv, static_cast<size_t>(nc) * ld));
-    HF_TRY(dev_alloc(ctx, &d_prow, 2 * static_cast<size_t>(nc)));
-    HF_TRY(dev_alloc(ctx, &d_pcol, static_cast<size_t>(nc)));
-    HF_HIP(copy_sync(ctx, d_dense, dense.data(), sizeof(double) * dense.size(), hipMemcpyHostToDevice));
-    HF_HIP(copy_sync(ctx, d_inv, eye.data(), sizeof(double) * eye.size(), hipMemcpyHostToDevice));
-    const int gp = std::max(1, (nc + TPB - 1) / TPB);
-    const int ge = static_cast<int>(std::min<size_t>((static_cast<size_t>(nc) * nc + TPB - 1) / TPB, 4096));
-    for (int cpiv = 0; cpiv < nc; ++cpiv) {
-      hipLaunchKernelGGL(k_gj_pivot, dim3(gp), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, d_inv, d_prow, d_pcol);
-      hipLaunchKernelGGL(k_gj_elim, dim3(ge), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, d_inv, d_prow, d_pcol);
-    }
-    HF_HIP(hipGetLastError());
-    // rows re-pitched to the even leading dimension (zero pad column)
-    HF_HIP(hipMemsetAsync(ctx->d_coarse_inv, 0, sizeof(double) * nc * ld, ctx->stream));
-    HF_HIP(hipMemcpy2DAsync(ctx->d_coarse_inv, sizeof(double) * ld, d_inv, sizeof(double) * nc, sizeof(double) * nc, nc,
-                            hipMemcpyDeviceToDevice, ctx->stream));
-    HF_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->coarse_ld = ld;
-    ctx->coarse_n = nc;
-  }
-  ctx->amg_opc = H.op_complexity;
-  ctx->amg_ready = true;
-  ctx->amg_setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  return HF_OK;
-}
-
-// VMODE 0: y = A x, 1: y += A x, 2: y = b - A x, 3: y = x + w D^-1 (b - A x); LDS-staged kernel when the
-// matrix is big enough to fill the chip, sub-wave kernel otherwise.
-template <int VMODE>
-void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y, const double* b = nullptr,
-                const double* dinv = nullptr, double w = 0.0, double* xout = nullptr) {
-  if (m.rpc > 0) {
-    constexpr int SM = VMODE == 0 ? 0 : VMODE == 1 ? 6 : VMODE == 2 ? 3 : VMODE == 3 ? 4 : 7;
-    int grid = std::min(m.nchunks, MAXP);
-    if (grid >= 64) grid &= ~7;
-    hipLaunchKernelGGL(k_spmv<SM>, dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream, m.nrow,
-                       m.nchunks, m.rpc, m.ptr, m.idx, m.val, x, y, c->d_scal, static_cast<double*>(nullptr), b, dinv,
-                       xout, static_cast<double*>(nullptr), static_cast<double*>(nullptr), w, 0, 0);
-    return;
-  }
-  const int lanes = m.lanes;
-  const long long threads = static_cast<long long>(m.nrow) * lanes;
-  const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 2048)));
-#define HF_VEC(L) hipLaunchKernelGGL((k_spmv_vec<L, VMODE>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, m.val, x, y, b, dinv, w, c->d_scal, xout)
-  switch (lanes) {
-    case 4: HF_VEC(4); break;
-    case 8: HF_VEC(8); break;
-    case 16: HF_VEC(16); break;
-    case 32: HF_VEC(32); break;
-    default: HF_VEC(64); break;
-  }
-#undef HF_VEC
-}
-
-// z = B r: one V(1,1) cycle.  Fixed buffer roles (no pointer swaps, so captured graphs and eager
-// launches always agree): on entry d_z holds w0 D^-1 r (written by the update / start kernel); on exit
-// d_z2 holds z and part_rz[out_slot] the partials of r.z.  On every coarser level x carries the
-// pre-smoothed iterate plus the coarse correction and x2 the post-smoothed result (the coarsest
-// level's result is its x).
-void vcycle(hf_ctx* c, int out_slot) {
-  const int nl = static_cast<int>(c->amg.size());
-  DevLevel& L0 = c->amg[0];
-  if (nl == 1) {  // no coarse level: one more Jacobi sweep keeps the operator symmetric
-    launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
-    return;
-  }
-  launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r);                 // t = r - A z
-  launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);                                // b1 = R0 t
-  for (int l = 1; l + 1 < nl; ++l) {
-    DevLevel& L = c->amg[l];
-    launch_vec<4>(c, L.A, L.b, L.r, L.b, L.dinv, L.omega, L.x);                 // x_l = w D^-1 b_l ; r_l = b_l - A_l x_l
-    launch_vec<0>(c, L.R, L.r, c->amg[l + 1].b);                                // b_{l+1} = R_l r_l
-  }
-  {
-    DevLevel& Lc = c->amg[nl - 1];
-    if (c->coarse_n > 0) {
-      const int g = std::max(1, std::min((Lc.n + 1) / 2, 2048));
-      hipLaunchKernelGGL(k_dense_mv, dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv, Lc.b, Lc.x,
-                         c->d_scal);
-    } else {
-      const int g = std::max(1, std::min((Lc.n + TPB - 1) / TPB, 1024));
-      hipLaunchKernelGGL(k_scale, dim3(g), dim3(TPB), 0, c->stream, Lc.n, Lc.omega, Lc.dinv, Lc.b, Lc.x, c->d_scal);
-    }
-  }
-  for (int l = nl - 2; l >= 1; --l) {
-    DevLevel& L = c->amg[l];
-    const double* coarse = (l + 1 == nl - 1) ? c->amg[l + 1].x : c->amg[l + 1].x2;
-    launch_vec<1>(c, L.P, coarse, L.x);                                         // x_l += P_l x_{l+1}
-    launch_vec<3>(c, L.A, L.x, L.x2, L.b, L.dinv, L.omega);                     // post-smooth -> x2
-  }
-  launch_vec<1>(c, L0.P, (nl == 2) ? c->amg[1].x : c->amg[1].x2, c->d_z);       // z += P0 x_1
-  launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
-}
-
-// One multigrid-PCG iteration: iteration head (as above), update (alpha, x, r, z0 = w D^-1 r), V-cycle (z, r.z)
-void launch_amg_iteration(hf_ctx* c, int parity) {
-  const bool timed = c->prof && c->prof_used < PROF_PAIRS;
-  hipEvent_t e0 = timed ? c->prof_ev[2 * c->prof_used] : nullptr, e1 = timed ? c->prof_ev[2 * c->prof_used + 1] : nullptr;
-  launch_spmv<9>(c, c->d_A, c->d_z2, c->d_Ap, c->d_part_pAp, nullptr, c->d_p, c->d_part_rz, c->d_part_zz, 0.0, nullptr, e0,
-                 e1, parity);
-  if (timed) c->prof_used++;
-  hipLaunchKernelGGL(k_pcg_update_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
-                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, c->d_u, c->d_r, c->d_p, c->d_Ap, c->d_dinv,
-                     c->amg[0].omega, c->d_z);
-  vcycle(c, parity ^ 1);
-}
-
-int read_scal(hf_ctx* ctx) {
-  HF_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
-  HF_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->prof) {  // harvest the event pairs of this burst (only launches that really ran count)
-    for (int k = 0; k < ctx->prof_used; ++k) {
-      float ms = 0.f;
-      const bool ran = !ctx->h_scal->done || (ctx->prof_base + k) < ctx->h_scal->iters;
-      if (ran && hipEventElapsedTime(&ms, ctx->prof_ev[2 * k], ctx->prof_ev[2 * k + 1]) == hipSuccess) {
-        ctx->prof_spmv_ms += ms;
-        ctx->prof_spmv_n += 1;
-      }
-    }
-    ctx->prof_used = 0;
-  }
-  return HF_OK;
-}
-
-void drop_graphs(hf_ctx* ctx) {
-  for (auto& g : ctx->graphs)
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  ctx->graphs.clear();
-}
-
-// Executable graph holding `iters` (even) consecutive iterations of the loop for `sys`; captured on
-// first use, replayed afterwards.  Returns nullptr when capture is unavailable (the caller then
-// launches eagerly).
-hipGraphExec_t iteration_graph(hf_ctx* ctx, const LinSys& sys, bool use_amg, int iters) {
-  for (auto& g : ctx->graphs)
-    if (g.A == sys.A && g.dinv == sys.dinv && g.x == sys.x && g.b == sys.b && g.amg == use_amg && g.iters == iters)
-      return g.exec;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  const bool dbg = std::getenv("HEATFLOW_DEBUG") != nullptr;
-  if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-    if (dbg) fprintf(stderr, "[heatflow] graph capture could not start\n");
-    return nullptr;
-  }
-  for (int k = 0; k < iters; ++k) {
-    if (use_amg) launch_amg_iteration(ctx, k & 1);
-    else launch_pcg_iteration(ctx, sys, k & 1);
-  }
-  if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || graph == nullptr) {
-    if (dbg) fprintf(stderr, "[heatflow] graph capture failed\n");
-    return nullptr;
-  }
-  const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  size_t nnodes = 0;
-  (void)hipGraphGetNodes(graph, nullptr, &nnodes);
-  (void)hipGraphDestroy(graph);
-  if (dbg) fprintf(stderr, "[heatflow] graph of %d iterations: %zu nodes, instantiate %s\n", iters, nnodes, hipGetErrorString(e));
-  if (e != hipSuccess) return nullptr;
-  ctx->graphs.push_back({sys.A, sys.dinv, sys.x, sys.b, use_amg, iters, exec});
-  return exec;
-}
-
-// PCG on `sys` started from sys.x.  Jacobi: any system on the pattern; AMG: the main system only.
-// Iteration count / residual are left in h_scal; *pred carries the burst-size hint between calls.
-int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double atol, int max_it, int* pred) {
-  if (!use_amg) {
-    // r = b - A x, z = D^-1 r, r.z
-    launch_spmv<2>(ctx, sys.A, sys.x, ctx->d_r, ctx->d_part_rz, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn, 0.0,
-                   sys.dinv);
-    hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
-                       ctx->d_part_bn, ctx->d_scal);
-  } else {
-    // r = b - A x, z0 = w D^-1 r; tolerance; z = B r (V-cycle, r.z into slot 0)
-    HF_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(Scal), ctx->stream));   // done = 0 so the start kernels run
-    launch_spmv<5>(ctx, sys.A, sys.x, ctx->d_r, nullptr, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn,
-                   ctx->amg[0].omega);
-    hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
-                       ctx->d_part_bn, ctx->d_scal);
-    vcycle(ctx, 0);
-  }
-  HF_HIP(hipGetLastError());
-
-  int launched = 0;
-  if (*pred <= 0) {  // previous solve needed no iteration (e.g. constant field): look before launching
-    HF_TRY(read_scal(ctx));
-    if (ctx->h_scal->done == 1) return HF_OK;
-  }
-  // first burst: what the previous solve needed (the counts drift slowly), then check in small bursts
-  int burst = std::max(2, std::min(max_it, *pred > 0 ? *pred : (use_amg ? 8 : 32)));
-  // graph unit: 2 multigrid iterations (~40 kernels) or 16 Jacobi iterations (48 kernels) per replay
-  const int unit = use_amg ? 2 : 16;
-  hipGraphExec_t gexec = (ctx->use_graph && !ctx->prof) ? iteration_graph(ctx, sys, use_amg, unit) : nullptr;
-  while (true) {
-    burst += burst & 1;  // parity pairs
-    ctx->prof_base = launched;
-    if (gexec != nullptr) {
-      burst = ((burst + unit - 1) / unit) * unit;
-      for (int k = 0; k < burst; k += unit) HF_HIP(hipGraphLaunch(gexec, ctx->stream));
-    } else {
-      for (int k = 0; k < burst; ++k) {
-        if (use_amg) launch_amg_iteration(ctx, (launched + k) & 1);
-        else launch_pcg_iteration(ctx, sys, (launched + k) & 1);
-      }
-    }
-    launched += burst;
-    HF_HIP(hipGetLastError());
-    HF_TRY(read_scal(ctx));
-    if (ctx->h_scal->done) break;
-    if (launched >= max_it) break;
-    burst = std::min(std::max(use_amg ? 2 : 8, launched / 8), max_it - launched);
-    burst = std::max(burst, 2);
-  }
-  *pred = ctx->h_scal->iters;
-  if (ctx->h_scal->done == 2) return fail(ctx, HF_ERR_NOCONV, "PCG breakdown (p.Ap <= 0) after %d iterations", ctx->h_scal->iters);
-  if (!ctx->h_scal->done)
-    return fail(ctx, HF_ERR_NOCONV, "PCG not converged in %d iterations (rel. residual %.3e)", ctx->h_scal->iters,
-                std::sqrt(ctx->h_scal->zz / std::max(ctx->h_scal->bn2, 1e-300)));
-  return HF_OK;
-}
-
-// One time step with g already in d_g.  Leaves iteration count / residual in h_scal.
-int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
-  const int nb = ctx->nbc;
-  // b = M u^n   (assemble_vector, run_with_diamond.py:476); with a previous step available the same
-  // pass writes the extrapolated start vector 2 u^n - u^{n-1}, and the three state buffers rotate
-  if (ctx->extrapolate && ctx->have_prev) {
-    launch_spmv<8>(ctx, ctx->d_M, ctx->d_u, ctx->d_b, nullptr, ctx->d_uprev, ctx->d_ustart);
-    // u^{n-1} <- u^n, iterate <- start vector (copies, not pointer rotation: captured graphs hold d_u)
-    HF_HIP(hipMemcpyAsync(ctx->d_uprev, ctx->d_u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
-    HF_HIP(hipMemcpyAsync(ctx->d_u, ctx->d_ustart, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
-  } else {
-    launch_spmv<0>(ctx, ctx->d_M, ctx->d_u, ctx->d_b);
-    if (ctx->extrapolate) {         // keep u^n for the next step
-      HF_HIP(hipMemcpyAsync(ctx->d_uprev, ctx->d_u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
-      ctx->have_prev = true;
-    }
-  }
-  if (nb > 0) {
-    if (ctx->nlift_rows > 0)  // apply_lifting (:477)
-      hipLaunchKernelGGL(k_lift, dim3((ctx->nlift_rows + 255) / 256), dim3(256), 0, ctx->stream, ctx->nlift_rows,
-                         ctx->d_lift_rows, ctx->d_lift_ptr, ctx->d_lift_bc, ctx->d_lift_val, ctx->d_g, ctx->d_b);
-    // set_bc (:479); the same values seed the iterate
-    hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, ctx->d_g,
-                       ctx->d_b, ctx->d_u);
-  }
-  const LinSys sys{ctx->d_A, ctx->d_dinv, ctx->d_u, ctx->d_b};
-  const bool use_amg = ctx->precond == 1 && ctx->amg_ready;
-  int rc = pcg_solve(ctx, sys, use_amg, rtol, atol, max_it, &ctx->pred_iters);
-  if (rc == HF_ERR_NOCONV && use_amg && ctx->h_scal->done == 2) {
-    // breakdown inside the multigrid-preconditioned loop (p.Ap <= 0: the preconditioner was not SPD for
-    // this operator): finish the step with the Jacobi preconditioner from the current iterate - still on
-    // the GPU - and count the event
-    ctx->amg_fallbacks += 1;
-    int pred = 0;
-    rc = pcg_solve(ctx, sys, false, rtol, atol, max_it, &pred);
-  }
-  return rc;
-}
-
-int ensure_samples(hf_ctx* ctx, int ns) {
-  if (ns <= ctx->samp_cap) return HF_OK;
-  HF_TRY(dev_alloc(ctx, &ctx->d_samp_idx, ns));
-  HF_TRY(dev_alloc(ctx, &ctx->d_samp, ns));
-  ctx->samp_cap = ns;
-  return HF_OK;
-}
-
-int build_lift(hf_ctx* ctx) {
-  // Host: for every free row i and BC column j with A_ij in the pattern -> (row i, bc index of j, slot)
-  const int32_t n = ctx->n, nbc = ctx->nbc;
-  std::vector<int32_t> dofs(nbc);
-  HF_HIP(copy_sync(ctx, dofs.data(), ctx->d_bc_dofs, sizeof(int32_t) * nbc, hipMemcpyDeviceToHost));
-  std::vector<int32_t> bc_index(n, -1);
-  for (int32_t q = 0; q < nbc; ++q) bc_index[dofs[q]] = q;
-  // free rows adjacent to a BC dof = columns of the BC rows (pattern is symmetric)
-  std::vector<int32_t> rows;
-  for (int32_t q = 0; q < nbc; ++q) {
-    const int32_t j = dofs[q];
-    for (int32_t k = ctx->h_rowptr[j]; k < ctx->h_rowptr[j + 1]; ++k) {
-      const int32_t i = ctx->h_colidx[k];
-      if (bc_index[i] < 0) rows.push_back(i);
-    }
-  }
-  std::sort(rows.begin(), rows.end());
-  rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
-  std::vector<int32_t> ptr(rows.size() + 1, 0), lbc, lslot;
-  for (size_t r = 0; r < rows.size(); ++r) {
-    const int32_t i = rows[r];
-    for (int32_t k = ctx->h_rowptr[i]; k < ctx->h_rowptr[i + 1]; ++k) {
-      const int32_t q = bc_index[ctx->h_colidx[k]];
-      if (q >= 0) { lbc.push_back(q); lslot.push_back(k); }
-    }
-    ptr[r + 1] = static_cast<int32_t>(lbc.size());
-  }
-  ctx->nlift_rows = static_cast<int32_t>(rows.size());
-  ctx->nlift = static_cast<int32_t>(lbc.size());
-  HF_TRY(dev_alloc(ctx, &ctx->d_lift_rows, rows.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_lift_ptr, ptr.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_lift_bc, lbc.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_lift_slot, lslot.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_lift_val, lbc.size()));
-  if (!rows.empty()) HF_HIP(copy_sync(ctx, ctx->d_lift_rows, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice));
-  HF_HIP(copy_sync(ctx, ctx->d_lift_ptr, ptr.data(), sizeof(int32_t) * ptr.size(), hipMemcpyHostToDevice));
-  if (!lbc.empty()) {
-    HF_HIP(copy_sync(ctx, ctx->d_lift_bc, lbc.data(), sizeof(int32_t) * lbc.size(), hipMemcpyHostToDevice));
-    HF_HIP(copy_sync(ctx, ctx->d_lift_slot, lslot.data(), sizeof(int32_t) * lslot.size(), hipMemcpyHostToDevice));
-  }
-  return HF_OK;
-}
-
-}  // namespace
+//   assembly   per-element P1 kernel (r-weighted axisymmetric mass + stiffness), owner-computes
+//              scatter-add into a CSR slab staged in LDS, streamed out once        (hf_kernels.hpp)
+//   time step  b = M u^n (CSR SpMV) -> lifting -> set_bc -> PCG (CSR SpMV with LDS-staged products,
+//              wavefront shuffles + fixed-order block partials, device-resident scalars), Jacobi or
+//              smoothed-aggregation multigrid preconditioner         (hf_solver.hpp, amg_host.hpp)
+// One translation unit: hf_context.hpp -> hf_kernels.hpp -> hf_pattern.hpp -> hf_solver.hpp -> this file.
+// Reference semantics being reproduced: run_with_diamond.py:321-337 (forms), :381-394 (assemble
+// once, symmetric Dirichlet elimination, solve), :469-481 (loop body).
+
+#include "hf_solver.hpp"
 
 // ==========================================================================================
 // C ABI

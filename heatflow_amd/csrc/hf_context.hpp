@@ -1,0 +1,193 @@
+// hf_context.hpp - constants, the context struct and small host helpers of libheatflow_hip.so
+// (HIP/CDNA4 gfx950 implementation of include/heatflow_hip.h).
+//
+
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "amg_host.hpp"
+#include "heatflow_hip.h"
+
+namespace {
+
+constexpr int RB = 256;        // rows per chunk of the vector kernels
+#ifndef HF_RBA
+#define HF_RBA 256
+#endif
+constexpr int RBA = HF_RBA;    // CSR rows owned by one assembly workgroup (= its thread count); 512 measured 7 % slower
+constexpr int TPB = 256;       // threads per workgroup = 4 wavefronts of 64
+constexpr int NCOL = 32;       // max colours per row block (uint32 mask)
+#ifndef HF_UNROLL
+#define HF_UNROLL 4
+#endif
+constexpr int MAXP = 1024;     // max workgroups per launch = partial-sum slots per array
+constexpr int TS = 512;        // SpMV workgroup: 512 threads = 8 wavefronts own 512 consecutive rows per chunk
+                               // (4 such workgroups per CU = 32 waves/CU; measured 20 % faster than 256x16)
+
+struct Scal {                  // device-resident PCG scalars
+  double tol2;                 // (max(rtol*||D^-1 b||, atol))^2
+  double bn2;                  // ||D^-1 b||^2
+  double zz;                   // ||D^-1 r||^2 of the last iterate
+  int iters;
+  int done;                    // 0 running, 1 converged, 2 breakdown
+  int first;                   // 1 until the first update of a solve: the first direction is p = z (beta = 0)
+};
+
+}  // namespace
+
+struct hf_ctx {
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  double last_ms = 0.0;
+
+  int32_t n = 0, ne = 0, nbc = 0;
+  int64_t nnz = 0;
+  int nchunks = 0, P = 0;      // 256-row chunks and grid of the vector kernels / assembly
+  int nchunks_s = 0, Ps = 0;   // 512-row chunks and grid of the SpMV kernel (Ps <= P partials)
+  int max_chunk_nnz_s = 0;
+  bool have_mesh = false, have_mat = false, assembled = false;
+  double dt = 0.0;
+  int mode = 0;
+
+  // host copies of the pattern (needed to build lifting structures)
+  std::vector<int32_t> h_rowptr, h_colidx;
+  std::vector<char> h_tag_used;
+
+  // device: mesh
+  double2* d_zr = nullptr;
+  int4* d_elem = nullptr;
+  int tab_len = 0;
+  double *d_kappa = nullptr, *d_rhoc = nullptr;
+  // device: pattern + owner lists
+  int32_t *d_rowptr = nullptr, *d_colidx = nullptr;
+  int32_t *d_blk_eptr = nullptr, *d_blk_cptr = nullptr;
+  int2* d_blk_ent = nullptr;     // 3 x int2 per owner-list entry
+  int nblk_a = 0;
+  int max_blk_nnz = 0, ncolors = 0;
+  int64_t elist_len = 0;
+  // device: matrices
+  double *d_M = nullptr, *d_A = nullptr, *d_dinv = nullptr;
+  // device: Dirichlet
+  int32_t* d_bc_dofs = nullptr;
+  double* d_g = nullptr;
+  int32_t nlift_rows = 0, nlift = 0;
+  int32_t *d_lift_rows = nullptr, *d_lift_ptr = nullptr, *d_lift_bc = nullptr, *d_lift_slot = nullptr;
+  double* d_lift_val = nullptr;
+  // device: vectors
+  double *d_u = nullptr, *d_b = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr;
+  double *d_uprev = nullptr, *d_ustart = nullptr;   // u^{n-1} and the buffer of the next start vector (rotated with d_u)
+  bool have_prev = false;
+  int extrapolate = 1;         // start PCG from 2 u^n - u^{n-1} (same answer, fewer iterations)
+  double *d_tmp = nullptr;
+  // device: reductions
+  double *d_part_pAp = nullptr, *d_part_rz = nullptr, *d_part_zz = nullptr, *d_part_bn = nullptr;
+  Scal* d_scal = nullptr;
+  Scal* h_scal = nullptr;      // pinned
+  int32_t* d_samp_idx = nullptr;
+  double* d_samp = nullptr;
+  int samp_cap = 0;
+  int pred_iters = 0;
+  // multigrid preconditioner (hf_set_precond): device hierarchy
+  int precond = 0;             // 0 Jacobi, 1 smoothed-aggregation AMG V(1,1)
+  int amg_reuse = 0;           // 1: keep the coarse levels across hf_assemble calls (kappa sweeps)
+  bool amg_ready = false;
+  struct DevCsr {
+    int nrow = 0, ncol = 0, lanes = 8; int64_t nnz = 0; int32_t *ptr = nullptr, *idx = nullptr; double* val = nullptr;
+    int rpc = 0, nchunks = 0, chunk_nnz = 0;   // LDS-staged (stream) kernel geometry; rpc = 0 -> use the sub-wave kernel
+  };
+  struct DevLevel { DevCsr A, P, R; double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr; double omega = 0; int n = 0; };
+  std::vector<DevLevel> amg;
+  double* d_coarse_inv = nullptr;
+  int coarse_n = 0, coarse_ld = 0;   // dense inverse, row-major with an even leading dimension (16-byte row loads)
+  double amg_opc = 0.0, amg_setup_s = 0.0;
+  long long amg_fallbacks = 0;   // steps finished by Jacobi-PCG after a multigrid-PCG breakdown
+  double *d_z = nullptr, *d_z2 = nullptr;
+  // read-flux projection (hf_flux_setup): unit-rho_c r-weighted mass matrix and the projected gradient
+  bool flux_ready = false;
+  double *d_M1 = nullptr, *d_dinv1 = nullptr, *d_gz = nullptr, *d_gr = nullptr, *d_bz = nullptr, *d_br = nullptr;
+  int pred_flux[2] = {0, 0};
+  // hipGraph replay of the PCG loops: one executable graph per (system, preconditioner), each holding
+  // an even number of iterations (all host-side pointer swaps return to their start after two)
+  struct IterGraph { const double* A; const double* dinv; double* x; const double* b; bool amg; int iters; hipGraphExec_t exec; };
+  std::vector<IterGraph> graphs;
+  bool use_graph = false;      // opt-in (HEATFLOW_GRAPH=1): on this stack the loop is device-bound, replay measured no gain,
+                               // and rocprofv3 --kernel-trace crashes on long runs of graph replays
+  // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
+  bool prof = false;
+  std::vector<hipEvent_t> prof_ev;
+  int prof_used = 0, prof_base = 0;
+  double prof_spmv_ms = 0.0;
+  long long prof_spmv_n = 0;
+};
+
+namespace {
+
+int fail(hf_ctx* c, int code, const char* fmt, ...);
+
+hipError_t copy_sync(hf_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  if (bytes == 0) return hipSuccess;
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
+
+int fail(hf_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+#define HF_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(ctx, HF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+int dev_alloc(hf_ctx* ctx, T** p, size_t count) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+  if (e != hipSuccess) return fail(ctx, HF_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  return HF_OK;
+}
+#define HF_TRY(expr) do { int rc_ = (expr); if (rc_ != HF_OK) return rc_; } while (0)
+
+// Host<->device copy that is complete on return, issued on the context's own stream (never the legacy
+// stream: contexts on other threads may be capturing graphs, which a legacy-stream copy would break).
+hipError_t copy_sync(hf_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+
+template <typename T>
+void dev_free(T** p) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+// Scratch device buffer released on every exit path of the function that owns it.
+template <typename T>
+struct DevTemp {
+  T* p = nullptr;
+  ~DevTemp() { dev_free(&p); }
+  DevTemp() = default;
+  DevTemp(const DevTemp&) = delete;
+  DevTemp& operator=(const DevTemp&) = delete;
+};
+
+}  // namespace

@@ -1,0 +1,687 @@
+// Part of libheatflow_hip.so (see heatflow_hip.hip): device code - element assembly, CSR SpMV (LDS-staged and sub-wave), PCG and multigrid kernels
+#pragma once
+#include "hf_context.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+
+// Sum over the 256 threads of a workgroup, identical order every run: 64-lane shuffle tree
+// per wavefront, then the four wave sums added in wave order.  Every thread gets the sum.
+template <int NW = 4>
+__device__ __forceinline__ double block_sum(double v, double* sw) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sw[w] = v;
+  __syncthreads();
+  double t = sw[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) t += sw[k];
+  __syncthreads();
+  return t;
+}
+
+// Fixed-order sum of the P per-workgroup partials written by the previous kernel.
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int P, double* s4) {
+  double v = 0.0;
+  for (int k = threadIdx.x; k < P; k += TPB) v += part[k];
+  return block_sum(v, s4);
+}
+
+// Chunk schedule of the row-chunked kernels.  Workgroups are dealt round-robin over the 8 XCDs
+// (blockIdx % 8 says which blocks share an XCD and its L2; speed only, never correctness), so with
+// HF_XCD_MAP each XCD group walks one contiguous eighth of the chunk range: spatially adjacent chunks
+// (Morton order) then share an L2, which keeps the SpMV's neighbour gathers and a chunk's vector
+// slices from kernel to kernel on the same XCD.  Every kernel uses the same schedule.
+#ifndef HF_XCD_MAP
+#define HF_XCD_MAP 1
+#endif
+struct ChunkIter {
+  int chunk, step, end;
+  __device__ __forceinline__ ChunkIter(int nchunks) {
+    if (HF_XCD_MAP && (gridDim.x & 7) == 0) {
+      const int per = (nchunks + 7) >> 3;
+      const int xcd = blockIdx.x & 7;
+      chunk = xcd * per + (blockIdx.x >> 3);
+      step = gridDim.x >> 3;
+      end = min(nchunks, (xcd + 1) * per);
+    } else {
+      chunk = blockIdx.x;
+      step = gridDim.x;
+      end = nchunks;
+    }
+  }
+};
+
+// r-weighted P1 element matrices (reference forms run_with_diamond.py:328-331).
+//   M_ii = rho_c |K| (3 r_i + r_j + r_k)/30,  M_ij = rho_c |K| (2 r_i + 2 r_j + r_k)/60
+//   K_ij = kappa |K| rbar (b_i b_j + c_i c_j)/d^2, d = 2*signed area, rbar = mean r
+// m[] / k[] hold the symmetric 3x3 as {00, 11, 22, 01, 02, 12}.
+__device__ __forceinline__ void element_local(const double2 p0, const double2 p1, const double2 p2, double rho_c,
+                                              double kappa, double m[6], double k[6]) {
+  // No FMA contraction here: the same element is evaluated by different workgroups (and by
+  // different unrolled copies of the caller); every evaluation must give the same bits so that the
+  // assembled matrices stay exactly symmetric.
+#pragma clang fp contract(off)
+  const double d = (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+  const double area = 0.5 * fabs(d);
+  const double b0 = p1.y - p2.y, b1 = p2.y - p0.y, b2 = p0.y - p1.y;
+  const double c0 = p2.x - p1.x, c1 = p0.x - p2.x, c2 = p1.x - p0.x;
+  const double rsum = (p0.y + p1.y) + p2.y;
+  const double ks = kappa * area * (rsum / 3.0) / (d * d);
+  k[0] = ks * (b0 * b0 + c0 * c0);
+  k[1] = ks * (b1 * b1 + c1 * c1);
+  k[2] = ks * (b2 * b2 + c2 * c2);
+  k[3] = ks * (b0 * b1 + c0 * c1);
+  k[4] = ks * (b0 * b2 + c0 * c2);
+  k[5] = ks * (b1 * b2 + c1 * c2);
+  const double ms = rho_c * area;
+  m[0] = ms * ((2.0 * p0.y + rsum) / 30.0);
+  m[1] = ms * ((2.0 * p1.y + rsum) / 30.0);
+  m[2] = ms * ((2.0 * p2.y + rsum) / 30.0);
+  m[3] = ms * ((rsum + p0.y + p1.y) / 60.0);
+  m[4] = ms * ((rsum + p0.y + p2.y) / 60.0);
+  m[5] = ms * ((rsum + p1.y + p2.y) / 60.0);
+}
+
+__device__ __forceinline__ int sym_index(int a, int b) {  // (a,b) -> slot in {00,11,22,01,02,12}
+  return a == b ? a : (a + b + 2);                        // 01->3, 02->4, 12->5
+}
+
+// ------------------------------------------------------------------------------------------
+// Assembly, LDS-staged owner-computes.  Workgroup `blk` owns rows [blk*RBA, blk*RBA+RBA): it
+// stages that slab of M and A (values) plus its column indices in LDS, walks the elements
+// incident to its rows (precomputed list; an element on a block boundary is visited by each
+// owning block, which adds only the rows it owns), and writes the slab out coalesced.
+//   COLORED = false: LDS f64 atomics (ds_add_f64), any order
+//   COLORED = true : elements grouped by colour (no two share an owned row), plain RMW,
+//                    barrier between colours -> bitwise reproducible
+// ------------------------------------------------------------------------------------------
+// One list entry = 24 bytes = three int2: (n0, n1) (n2, tag<<11 | owned<<8 | off8) (off0..3, off4..7):
+// the element record and the offsets of its nine contributions (a,b) = (0,0) (0,1) ... (2,2) inside
+// the CSR rows of its nodes; `owned` marks the nodes whose rows this workgroup owns.
+struct AsmEntry { int n0, n1, n2; unsigned w3, off03, off47; };
+
+__device__ __forceinline__ AsmEntry load_entry(const int2* __restrict__ ent, int q) {
+  const int2 a = ent[3 * q], b = ent[3 * q + 1], c = ent[3 * q + 2];
+  return AsmEntry{a.x, a.y, b.x, static_cast<unsigned>(b.y), static_cast<unsigned>(c.x), static_cast<unsigned>(c.y)};
+}
+
+template <bool COLORED>
+__global__ __launch_bounds__(RBA) void k_assemble_lds(int n, int cap, const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ blk_eptr,
+                                                      const int32_t* __restrict__ blk_cptr,
+                                                      const int2* __restrict__ blk_ent,
+                                                      const double2* __restrict__ zr,
+                                                      const double* __restrict__ kappa_tab,
+                                                      const double* __restrict__ rhoc_tab, double dt,
+                                                      double* __restrict__ Mv, double* __restrict__ Av) {
+  extern __shared__ double smem[];
+  double* sM = smem;
+  double* sA = smem + cap;
+  int* sR = reinterpret_cast<int*>(smem + 2 * cap);
+
+  const int blk = blockIdx.x;
+  const int r0 = blk * RBA;
+  const int r1 = min(n, r0 + RBA);
+  const int k0 = rowptr[r0];
+  const int nk = rowptr[r1] - k0;
+  for (int k = threadIdx.x; k < nk; k += RBA) {
+    sM[k] = 0.0;
+    sA[k] = 0.0;
+  }
+  for (int k = threadIdx.x; k <= r1 - r0; k += RBA) sR[k] = rowptr[r0 + k] - k0;
+  __syncthreads();
+
+  auto scatter = [&](const AsmEntry e, const double2 p0, const double2 p1, const double2 p2) {
+    double m[6], kk[6], av6[6];
+    const int tag = static_cast<int>(e.w3 >> 11);
+    element_local(p0, p1, p2, rhoc_tab[tag], kappa_tab[tag], m, kk);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) av6[q] = fma(dt, kk[q], m[q]);  // once per unique entry, explicit FMA: same bits everywhere
+    const int nd[3] = {e.n0, e.n1, e.n2};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (!((e.w3 >> (8 + a)) & 1u)) continue;
+      const int base = sR[nd[a] - r0];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int q9 = a * 3 + b;
+        const unsigned off = q9 < 4 ? (e.off03 >> (8 * q9)) & 0xFFu : q9 < 8 ? (e.off47 >> (8 * (q9 - 4))) & 0xFFu : e.w3 & 0xFFu;
+        const int slot = base + static_cast<int>(off);
+        const int q = sym_index(a, b);
+        if (COLORED) {
+          sM[slot] += m[q];
+          sA[slot] += av6[q];
+        } else {
+          atomicAdd(&sM[slot], m[q]);
+          atomicAdd(&sA[slot], av6[q]);
+        }
+      }
+    }
+  };
+  // The list is laid out per workgroup and streamed coalesced; only the coordinates are gathered.
+  // Three elements in flight per lane: all loads are issued before the first scatter.
+  constexpr int NF = 3;
+  auto run_range = [&](int e0, int e1) {
+    for (int k = e0 + threadIdx.x; k < e1; k += NF * RBA) {
+      AsmEntry e[NF];
+      double2 pa[NF], pb[NF], pc[NF];
+#pragma unroll
+      for (int u = 0; u < NF; ++u) e[u] = load_entry(blk_ent, min(k + u * RBA, e1 - 1));
+#pragma unroll
+      for (int u = 0; u < NF; ++u) { pa[u] = zr[e[u].n0]; pb[u] = zr[e[u].n1]; pc[u] = zr[e[u].n2]; }
+#pragma unroll
+      for (int u = 0; u < NF; ++u)
+        if (k + u * RBA < e1) scatter(e[u], pa[u], pb[u], pc[u]);
+    }
+  };
+
+  if (COLORED) {
+    const int32_t* cp = blk_cptr + static_cast<size_t>(blk) * (NCOL + 1);
+    for (int c = 0; c < NCOL; ++c) {
+      const int e0 = cp[c], e1 = cp[c + 1];
+      if (e0 == e1) { if (e1 == cp[NCOL]) break; else continue; }
+      run_range(e0, e1);
+      __syncthreads();
+    }
+  } else {
+    run_range(blk_eptr[blk], blk_eptr[blk + 1]);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nk; k += RBA) {
+    Mv[k0 + k] = sM[k];
+    Av[k0 + k] = sA[k];
+  }
+}
+
+// Baseline: one thread per element, f64 atomics into global CSR (values must be zeroed).
+__global__ __launch_bounds__(TPB) void k_assemble_global(int ne, const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ colidx,
+                                                         const int4* __restrict__ elem,
+                                                         const double2* __restrict__ zr,
+                                                         const double* __restrict__ kappa_tab,
+                                                         const double* __restrict__ rhoc_tab, double dt,
+                                                         double* __restrict__ Mv, double* __restrict__ Av) {
+  const int e = blockIdx.x * TPB + threadIdx.x;
+  if (e >= ne) return;
+  const int4 el = elem[e];
+  const int nd[3] = {el.x, el.y, el.z};
+  double m[6], kk[6], av6[6];
+  element_local(zr[el.x], zr[el.y], zr[el.z], rhoc_tab[el.w], kappa_tab[el.w], m, kk);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) av6[q] = fma(dt, kk[q], m[q]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int s0 = rowptr[nd[a]], s1 = rowptr[nd[a] + 1];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      int s = s0;
+      while (s < s1 && colidx[s] != nd[b]) ++s;
+      const int q = sym_index(a, b);
+      atomicAdd(&Mv[s], m[q]);
+      atomicAdd(&Av[s], av6[q]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Read-flux projection (reference run_no_diamond.py:479-489, 544-550): L2 projection of grad T
+// onto vector P1 with the r-weighted mass matrix.  The reference solves one 2n x 2n system; the
+// components decouple into two scalar solves with M_r(1).  This kernel forms both right-hand
+// sides  b_c[i] = sum_e (d_c T)_e * int_e phi_i r dx,  int_e phi_i r = |K| (2 r_i + r_j + r_k)/12,
+// owner-computes like the assembly: a workgroup owns RBA rows and adds the incident elements.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RBA) void k_grad_rhs(int n, const int32_t* __restrict__ blk_eptr,
+                                                  const int2* __restrict__ blk_ent, const double2* __restrict__ zr,
+                                                  const double* __restrict__ u, double* __restrict__ bz,
+                                                  double* __restrict__ br) {
+  __shared__ double sB[2 * RBA];
+  const int blk = blockIdx.x;
+  const int r0 = blk * RBA;
+  const int r1 = min(n, r0 + RBA);
+  for (int k = threadIdx.x; k < 2 * RBA; k += RBA) sB[k] = 0.0;
+  __syncthreads();
+  for (int q = blk_eptr[blk] + threadIdx.x; q < blk_eptr[blk + 1]; q += RBA) {
+#pragma clang fp contract(off)
+    const AsmEntry e = load_entry(blk_ent, q);
+    const double2 p0 = zr[e.n0], p1 = zr[e.n1], p2 = zr[e.n2];
+    const double u0 = u[e.n0], u1 = u[e.n1], u2 = u[e.n2];
+    const double d = (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+    const double area = 0.5 * fabs(d);
+    // grad phi_i = (b_i, c_i)/d
+    const double gz = (u0 * (p1.y - p2.y) + u1 * (p2.y - p0.y) + u2 * (p0.y - p1.y)) / d;
+    const double gr = (u0 * (p2.x - p1.x) + u1 * (p0.x - p2.x) + u2 * (p1.x - p0.x)) / d;
+    const double rsum = (p0.y + p1.y) + p2.y;
+    const double wgt[3] = {area * (p0.y + rsum) / 12.0, area * (p1.y + rsum) / 12.0, area * (p2.y + rsum) / 12.0};
+    const int nd[3] = {e.n0, e.n1, e.n2};
+    const unsigned owned = (e.w3 >> 8) & 7u;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (!((owned >> a) & 1u)) continue;
+      atomicAdd(&sB[2 * (nd[a] - r0)], gz * wgt[a]);
+      atomicAdd(&sB[2 * (nd[a] - r0) + 1], gr * wgt[a]);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < r1 - r0; k += RBA) {
+    bz[r0 + k] = sB[2 * k];
+    br[r0 + k] = sB[2 * k + 1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dirichlet elimination (what dolfinx assemble_matrix(form, bcs) leaves): BC rows and
+// columns zeroed, unit diagonal.  The column entries A[i, j in B] of free rows i are saved
+// first - they are the lifting operator of apply_lifting (run_with_diamond.py:477).
+// ------------------------------------------------------------------------------------------
+__global__ void k_take_lift(int nlift, const int32_t* __restrict__ slot, double* __restrict__ A,
+                            double* __restrict__ val) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nlift) return;
+  val[q] = A[slot[q]];
+  A[slot[q]] = 0.0;
+}
+
+__global__ void k_bc_rows(int nbc, const int32_t* __restrict__ dofs, const int32_t* __restrict__ rowptr,
+                          const int32_t* __restrict__ colidx, double* __restrict__ A) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nbc) return;
+  const int row = dofs[q];
+  for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) A[k] = (colidx[k] == row) ? 1.0 : 0.0;
+}
+
+__global__ void k_dinv(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                       const double* __restrict__ A, double* __restrict__ dinv) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  double d = 0.0;
+  for (int k = rowptr[row]; k < rowptr[row + 1]; ++k)
+    if (colidx[k] == row) d = A[k];
+  dinv[row] = 1.0 / d;
+}
+
+// b[row] -= sum_q lift_val[q] * g[lift_bc[q]]   (fixed order -> reproducible)
+__global__ void k_lift(int nrows, const int32_t* __restrict__ rows, const int32_t* __restrict__ ptr,
+                       const int32_t* __restrict__ bc, const double* __restrict__ val,
+                       const double* __restrict__ g, double* __restrict__ b) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nrows) return;
+  double s = 0.0;
+  for (int k = ptr[q]; k < ptr[q + 1]; ++k) s += val[k] * g[bc[k]];
+  b[rows[q]] -= s;
+}
+
+// set_bc on the right-hand side and on the PCG start vector (u_B = g)
+__global__ void k_set_bc(int nbc, const int32_t* __restrict__ dofs, const double* __restrict__ g,
+                         double* __restrict__ b, double* __restrict__ u) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nbc) return;
+  b[dofs[q]] = g[q];
+  u[dofs[q]] = g[q];
+}
+
+__global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* __restrict__ u,
+                         double* __restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < ns) out[q] = u[idx[q]];
+}
+
+// ------------------------------------------------------------------------------------------
+// CSR SpMV, LDS-staged ("CSR-stream"): a workgroup takes chunks of RB consecutive rows; all
+// 256 lanes stream the chunk's values and column indices in nnz order (fully coalesced) and
+// park val*x[col] in LDS; then lane t sums the products of row t in column order.  The
+// summation order per row is the CSR order -> bitwise reproducible, no atomics.
+//   MODE 0: y = A x
+//   MODE 1: y = A x and partial sums of x.y             (PCG: Ap, p.Ap)
+//   MODE 2: r = b - A x; p = D^-1 r; partials r.p, p.p, (D^-1 b)^2   (PCG start)
+//   MODE 3: y = b - A x                                              (multigrid residual)
+//   MODE 4: y = x + w D^-1 (b - A x), partials b.y                   (damped-Jacobi sweep, fused r.z)
+//   MODE 5: y = b - A x; p = w D^-1 y; partials (D^-1 y)^2, (D^-1 b)^2   (AMG-PCG start)
+//   MODE 6: y += A x                                                 (multigrid prolongation)
+//   MODE 7: p = w D^-1 b; y = b - A p   (first Jacobi sweep from zero fused with the residual;
+//           the products gather w*dinv[col]*b[col], so p is never read back)
+//   MODE 8: y = A x; p = 2 x - b        (RHS b = M u^n fused with the extrapolated start
+//           2 u^n - u^{n-1} of the next solve; `b` carries u^{n-1})
+//   MODE 9: PCG iteration head (x = z): convergence test, beta, Ap <- A z + beta Ap, p <- z + beta p,
+//           p.Ap partials - SpMV and direction update in one pass
+// The chunk is `rpc` rows (512 for the fine operator; fewer for long-row transfer operators so
+// that a chunk's products fit the 64-KB LDS window).
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows per chunk, <= TS */,
+                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                              const double* __restrict__ vals, const double* __restrict__ x,
+                                              double* __restrict__ y, Scal* __restrict__ scal,
+                                              double* __restrict__ part0, const double* __restrict__ bvec,
+                                              const double* __restrict__ dinv, double* __restrict__ pvec,
+                                              double* __restrict__ part1, double* __restrict__ part2, double w,
+                                              int npart /* partial slots the consumers sum (>= gridDim.x) */,
+                                              int parity) {
+  extern __shared__ double sprod[];
+  __shared__ double s4[TS / 64];
+  if ((MODE == 1 || MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 9) && scal->done) return;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  double beta = 0.0;
+  bool first9 = false;
+  if (MODE == 9) {
+    first9 = scal->first != 0;
+    // PCG iteration head: x = z (preconditioned residual).  Convergence test on the (D^-1 r)^2 partials
+    // of the last update, beta = r.z(new)/r.z(old) from the two parity slots (part1), then in the row
+    // loop  Ap <- A z + beta Ap,  p <- z + beta p  (direction update by recurrence) and p.Ap partials.
+    if (!first9) {
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+      for (int k = threadIdx.x; k < npart; k += TS) {
+        v0 += part1[parity * MAXP + k];
+        v1 += part1[(parity ^ 1) * MAXP + k];
+        v2 += part2[k];
+      }
+      const double rz_new = block_sum<TS / 64>(v0, s4);
+      const double rz_old = block_sum<TS / 64>(v1, s4);
+      const double zz = block_sum<TS / 64>(v2, s4);
+      const bool conv = zz <= scal->tol2;
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal->zz = zz;
+        if (conv) scal->done = 1;
+      }
+      if (conv) return;
+      beta = rz_new / rz_old;
+    }
+  }
+  const ChunkIter sched(nchunks);
+  for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
+    const int r0 = chunk * rpc;
+    const int r1 = min(n, r0 + rpc);
+    const int k0 = rowptr[r0];
+    const int k1 = rowptr[r1];
+    if (MODE != 7) {  // products in nnz order; HF_UNROLL independent value/index loads and gathers in flight per lane
+      int k = k0 + threadIdx.x;
+      for (; k + (HF_UNROLL - 1) * TS < k1; k += HF_UNROLL * TS) {
+        int c[HF_UNROLL];
+        double v[HF_UNROLL], xv[HF_UNROLL];
+#pragma unroll
+        for (int u = 0; u < HF_UNROLL; ++u) { c[u] = colidx[k + u * TS]; v[u] = vals[k + u * TS]; }
+#pragma unroll
+        for (int u = 0; u < HF_UNROLL; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < HF_UNROLL; ++u) sprod[k - k0 + u * TS] = v[u] * xv[u];
+      }
+      for (; k < k1; k += TS) sprod[k - k0] = vals[k] * x[colidx[k]];
+    }
+    if (MODE == 7) {  // operand is w D^-1 b, formed on the fly
+      for (int k = k0 + threadIdx.x; k < k1; k += TS) {
+        const int c = colidx[k];
+        sprod[k - k0] = vals[k] * (w * dinv[c] * bvec[c]);
+      }
+    }
+    __syncthreads();
+    const int row = r0 + threadIdx.x;
+    if (row < r1) {
+      const int a = rowptr[row] - k0, b = rowptr[row + 1] - k0;
+      double s = 0.0;
+      for (int j = a; j < b; ++j) s += sprod[j];
+      if (MODE == 0) {
+        y[row] = s;
+      } else if (MODE == 1) {
+        y[row] = s;
+        acc0 += x[row] * s;
+      } else if (MODE == 2) {
+        const double bi = bvec[row], di = dinv[row];
+        const double ri = bi - s;
+        const double zi = di * ri;
+        y[row] = ri;
+        pvec[row] = zi;
+        acc0 += ri * zi;
+        acc1 += zi * zi;
+        acc2 += (di * bi) * (di * bi);
+      } else if (MODE == 3) {
+        y[row] = bvec[row] - s;
+      } else if (MODE == 4) {
+        const double bi = bvec[row];
+        const double yi = x[row] + w * dinv[row] * (bi - s);
+        y[row] = yi;
+        acc0 += bi * yi;
+      } else if (MODE == 5) {
+        const double bi = bvec[row], di = dinv[row];
+        const double ri = bi - s;
+        y[row] = ri;
+        pvec[row] = w * di * ri;
+        acc1 += (di * ri) * (di * ri);
+        acc2 += (di * bi) * (di * bi);
+      } else if (MODE == 6) {
+        y[row] += s;
+      } else if (MODE == 7) {
+        const double bi = bvec[row];
+        pvec[row] = w * dinv[row] * bi;
+        y[row] = bi - s;
+      } else if (MODE == 8) {
+        y[row] = s;
+        pvec[row] = 2.0 * x[row] - bvec[row];
+      } else {
+        const double api = first9 ? s : s + beta * y[row];          // first iteration: p = z, Ap = A z
+        const double pi = first9 ? x[row] : x[row] + beta * pvec[row];
+        y[row] = api;
+        pvec[row] = pi;
+        acc0 += pi * api;
+      }
+    }
+    __syncthreads();
+  }
+  // consumers sum `npart` slots in a fixed order; this launch has fewer workgroups, the rest are zeros
+  if (MODE == 1 || MODE == 2 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {
+    const double t0 = block_sum<TS / 64>(acc0, s4);
+    if (threadIdx.x == 0) {
+      part0[blockIdx.x] = t0;
+      for (int q = blockIdx.x + gridDim.x; q < npart; q += gridDim.x) part0[q] = 0.0;
+    }
+  }
+  if (MODE == 2 || MODE == 5) {
+    const double t1 = block_sum<TS / 64>(acc1, s4);
+    const double t2 = block_sum<TS / 64>(acc2, s4);
+    if (threadIdx.x == 0) {
+      part1[blockIdx.x] = t1;
+      part2[blockIdx.x] = t2;
+      for (int q = blockIdx.x + gridDim.x; q < npart; q += gridDim.x) { part1[q] = 0.0; part2[q] = 0.0; }
+    }
+  }
+}
+
+// PCG start: tolerance and convergence of the initial iterate (one workgroup).
+__global__ __launch_bounds__(TPB) void k_pcg_begin(int P, double rtol, double atol, const double* __restrict__ part_zz,
+                                                   const double* __restrict__ part_bn, Scal* __restrict__ scal) {
+  __shared__ double s4[4];
+  const double zz = sum_partials(part_zz, P, s4);
+  const double bn2 = sum_partials(part_bn, P, s4);
+  if (threadIdx.x == 0) {
+    const double tol = fmax(rtol * sqrt(bn2), atol);
+    scal->tol2 = tol * tol;
+    scal->bn2 = bn2;
+    scal->zz = zz;
+    scal->iters = 0;
+    scal->first = 1;
+    scal->done = (zz <= tol * tol) ? 1 : 0;
+  }
+}
+
+// x += alpha p; r -= alpha Ap; z = D^-1 r; partials r.z (into the other parity slot), z.z
+__global__ __launch_bounds__(TPB) void k_pcg_update(int n, int nchunks, int P, int parity, Scal* __restrict__ scal,
+                                                    const double* __restrict__ part_pAp, double* __restrict__ part_rz,
+                                                    double* __restrict__ part_zz, double* __restrict__ x,
+                                                    double* __restrict__ r, const double* __restrict__ p,
+                                                    const double* __restrict__ Ap, const double* __restrict__ dinv,
+                                                    double* __restrict__ z) {
+  __shared__ double s4[4];
+  if (scal->done) return;
+  const double pAp = sum_partials(part_pAp, P, s4);
+  const double rz = sum_partials(part_rz + parity * MAXP, P, s4);
+  if (!(pAp > 0.0)) {                                   // breakdown (A_hat is SPD, so only on NaN/garbage)
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal->done = 2;
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scal->iters += 1; scal->first = 0; }
+  const double alpha = rz / pAp;
+  double a_rz = 0.0, a_zz = 0.0;
+  const ChunkIter sched(nchunks);
+  for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
+    const int i = chunk * RB + threadIdx.x;
+    if (i < n) {
+      const double ri = r[i] - alpha * Ap[i];
+      const double zi = dinv[i] * ri;
+      x[i] += alpha * p[i];
+      r[i] = ri;
+      z[i] = zi;
+      a_rz += ri * zi;
+      a_zz += zi * zi;
+    }
+  }
+  const double t0 = block_sum(a_rz, s4);
+  const double t1 = block_sum(a_zz, s4);
+  if (threadIdx.x == 0) {
+    part_rz[(parity ^ 1) * MAXP + blockIdx.x] = t0;
+    part_zz[blockIdx.x] = t1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic CSR SpMV for the multigrid transfer operators and coarse levels: LANES lanes of a
+// wavefront share one row (4..64 by the average row length), fixed-order shuffle reduction.
+//   VMODE 0: y = A x      1: y += A x      2: y = b - A x      3: y = x + w D^-1 (b - A x)
+//   VMODE 4: xs = w D^-1 b (stored to xout), y = b - A xs
+// ------------------------------------------------------------------------------------------
+template <int LANES, int VMODE>
+__global__ __launch_bounds__(TPB) void k_spmv_vec(int nrow, const int32_t* __restrict__ ptr,
+                                                  const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                  const double* __restrict__ x, double* __restrict__ y,
+                                                  const double* __restrict__ b, const double* __restrict__ dinv,
+                                                  double w, const Scal* __restrict__ scal, double* __restrict__ xout) {
+  if (scal->done) return;
+  const int lane = threadIdx.x % LANES;
+  const int rows_per_pass = (gridDim.x * TPB) / LANES;
+  for (int row = (blockIdx.x * TPB + threadIdx.x) / LANES; row < nrow; row += rows_per_pass) {
+    double s = 0.0;
+    const int k1 = ptr[row + 1];
+    if (VMODE == 4) {
+      for (int k = ptr[row] + lane; k < k1; k += LANES) { const int c = idx[k]; s += val[k] * (w * dinv[c] * b[c]); }
+    } else {
+      for (int k = ptr[row] + lane; k < k1; k += LANES) s += val[k] * x[idx[k]];
+    }
+#pragma unroll
+    for (int o = LANES / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LANES);
+    if (lane == 0) {
+      if (VMODE == 0) y[row] = s;
+      else if (VMODE == 1) y[row] += s;
+      else if (VMODE == 2) y[row] = b[row] - s;
+      else if (VMODE == 3) y[row] = x[row] + w * dinv[row] * (b[row] - s);
+      else { const double bi = b[row]; xout[row] = w * dinv[row] * bi; y[row] = bi - s; }
+    }
+  }
+}
+
+// x = w D^-1 b  (first damped-Jacobi sweep from a zero guess)
+__global__ __launch_bounds__(TPB) void k_scale(int n, double w, const double* __restrict__ dinv,
+                                               const double* __restrict__ b, double* __restrict__ x,
+                                               const Scal* __restrict__ scal) {
+  if (scal->done) return;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) x[i] = w * dinv[i] * b[i];
+}
+
+// x = Ainv b with the dense inverse of the coarsest operator (row-major, leading dimension ld, even):
+// two wavefronts per row, 16-byte loads, halves combined through LDS.
+__global__ __launch_bounds__(TPB) void k_dense_mv(int n, int ld, const double* __restrict__ Ainv,
+                                                  const double* __restrict__ b, double* __restrict__ x,
+                                                  const Scal* __restrict__ scal) {
+  __shared__ double half_sum[4];
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;            // 0..3: waves 0,1 -> row 2*blk, waves 2,3 -> row 2*blk + 1
+  const int npair = (n + 1) >> 1;
+  for (int pr = blockIdx.x; pr < npair; pr += gridDim.x) {
+    const int row = 2 * pr + (wave >> 1);
+    double s = 0.0;
+    if (row < n) {
+      const double2* arow = reinterpret_cast<const double2*>(Ainv + static_cast<size_t>(row) * ld);
+      const double2* bv = reinterpret_cast<const double2*>(b);
+      const int nv = ld >> 1;
+      for (int j = (wave & 1) * 64 + lane; j < nv; j += 128) {
+        const double2 a = arow[j];
+        const double2 v = bv[j];
+        s += a.x * v.x + a.y * v.y;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) half_sum[wave] = s;
+    __syncthreads();
+    if (lane == 0 && (wave & 1) == 0 && row < n) x[row] = half_sum[wave] + half_sum[wave + 1];
+    __syncthreads();
+  }
+}
+
+// Dense inverse of the coarsest operator on the GPU: Gauss-Jordan without pivoting (the operator
+// is SPD, its pivots stay positive).  Two launches per pivot; A is overwritten by the identity.
+__global__ __launch_bounds__(TPB) void k_gj_pivot(int n, int c, const double* __restrict__ A,
+                                                  const double* __restrict__ Inv, double* __restrict__ prow,
+                                                  double* __restrict__ pcol) {
+  const double piv = A[static_cast<size_t>(c) * n + c];
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) {
+    prow[j] = A[static_cast<size_t>(c) * n + j] / piv;
+    prow[n + j] = Inv[static_cast<size_t>(c) * n + j] / piv;
+    pcol[j] = A[static_cast<size_t>(j) * n + c];
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_gj_elim(int n, int c, double* __restrict__ A, double* __restrict__ Inv,
+                                                 const double* __restrict__ prow, const double* __restrict__ pcol) {
+  const size_t total = static_cast<size_t>(n) * n;
+  for (size_t q = static_cast<size_t>(blockIdx.x) * TPB + threadIdx.x; q < total; q += static_cast<size_t>(gridDim.x) * TPB) {
+    const int r = static_cast<int>(q / n), j = static_cast<int>(q % n);
+    if (r == c) {
+      A[q] = prow[j];
+      Inv[q] = prow[n + j];
+    } else {
+      const double f = pcol[r];
+      A[q] -= f * prow[j];
+      Inv[q] -= f * prow[n + j];
+    }
+  }
+}
+
+// AMG-PCG: x += alpha p; r -= alpha Ap; z0 = w D^-1 r (pre-smoothed start of the V-cycle);
+// partial (D^-1 r)^2 for the convergence test.  r.z comes from the V-cycle's last kernel.
+__global__ __launch_bounds__(TPB) void k_pcg_update_amg(int n, int nchunks, int P, int parity, Scal* __restrict__ scal,
+                                                        const double* __restrict__ part_pAp,
+                                                        const double* __restrict__ part_rz, double* __restrict__ part_zz,
+                                                        double* __restrict__ x, double* __restrict__ r,
+                                                        const double* __restrict__ p, const double* __restrict__ Ap,
+                                                        const double* __restrict__ dinv, double w, double* __restrict__ z0) {
+  __shared__ double s4[4];
+  if (scal->done) return;
+  const double pAp = sum_partials(part_pAp, P, s4);
+  const double rz = sum_partials(part_rz + parity * MAXP, P, s4);
+  if (!(pAp > 0.0)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal->done = 2;
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scal->iters += 1; scal->first = 0; }
+  const double alpha = rz / pAp;
+  double a_zz = 0.0;
+  const ChunkIter sched(nchunks);
+  for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
+    const int i = chunk * RB + threadIdx.x;
+    if (i < n) {
+      const double ri = r[i] - alpha * Ap[i];
+      const double zi = dinv[i] * ri;
+      x[i] += alpha * p[i];
+      r[i] = ri;
+      z0[i] = w * zi;
+      a_zz += zi * zi;
+    }
+  }
+  const double t1 = block_sum(a_zz, s4);
+  if (threadIdx.x == 0) part_zz[blockIdx.x] = t1;
+}
+
+}  // namespace

@@ -1,0 +1,193 @@
+// Part of libheatflow_hip.so (see heatflow_hip.hip): host code - sparsity pattern, owner lists and colouring, launch helpers of the Jacobi-PCG loop
+#pragma once
+#include "hf_kernels.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// host side: sparsity pattern, owner lists, colouring
+// ------------------------------------------------------------------------------------------
+struct Pattern {
+  std::vector<int32_t> rowptr, colidx, blk_eptr, blk_cptr, blk_elist;
+  std::vector<int2> blk_ent;       // 3 x int2 per list entry: element record + nine slot offsets + ownership mask
+  int max_blk_nnz = 0, ncolors = 0;
+};
+
+int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const int32_t* tag, Pattern& P) {
+  std::vector<int32_t> nptr(static_cast<size_t>(n) + 1, 0);
+  for (int64_t k = 0; k < 3LL * ne; ++k) nptr[tri[k] + 1]++;
+  for (int32_t i = 0; i < n; ++i) nptr[i + 1] += nptr[i];
+  std::vector<int32_t> nlist(static_cast<size_t>(3) * ne);
+  {
+    std::vector<int32_t> cur(nptr.begin(), nptr.end() - 1);
+    for (int32_t e = 0; e < ne; ++e)
+      for (int a = 0; a < 3; ++a) nlist[cur[tri[3 * e + a]]++] = e;
+  }
+  P.rowptr.assign(static_cast<size_t>(n) + 1, 0);
+  P.colidx.clear();
+  P.colidx.reserve(static_cast<size_t>(8) * n);
+  std::vector<int32_t> tmp;
+  for (int32_t i = 0; i < n; ++i) {
+    tmp.clear();
+    for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
+      const int32_t e = nlist[q];
+      tmp.push_back(tri[3 * e]); tmp.push_back(tri[3 * e + 1]); tmp.push_back(tri[3 * e + 2]);
+    }
+    if (tmp.empty()) return fail(ctx, HF_ERR_ARG, "node %d belongs to no triangle", i);
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    P.colidx.insert(P.colidx.end(), tmp.begin(), tmp.end());
+    if (P.colidx.size() > static_cast<size_t>(INT32_MAX)) return fail(ctx, HF_ERR_ARG, "nnz exceeds int32");
+    P.rowptr[i + 1] = static_cast<int32_t>(P.colidx.size());
+  }
+  // owner lists + greedy colouring per row block
+  const int nblk = (n + RBA - 1) / RBA;
+  P.blk_eptr.assign(static_cast<size_t>(nblk) + 1, 0);
+  P.blk_cptr.assign(static_cast<size_t>(nblk) * (NCOL + 1), 0);
+  P.blk_elist.clear();
+  P.blk_elist.reserve(static_cast<size_t>(ne) * 3 / 2);
+  std::vector<int32_t> stamp(ne, -1), list, color;
+  std::vector<uint32_t> mask(RBA);
+  P.max_blk_nnz = 0;
+  P.ncolors = 0;
+  for (int b = 0; b < nblk; ++b) {
+    const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
+    P.max_blk_nnz = std::max(P.max_blk_nnz, P.rowptr[r1] - P.rowptr[r0]);
+    list.clear();
+    for (int32_t i = r0; i < r1; ++i)
+      for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
+        const int32_t e = nlist[q];
+        if (stamp[e] != b) { stamp[e] = b; list.push_back(e); }
+      }
+    std::sort(list.begin(), list.end());
+    std::fill(mask.begin(), mask.end(), 0u);
+    color.resize(list.size());
+    int counts[NCOL] = {0};
+    for (size_t k = 0; k < list.size(); ++k) {
+      const int32_t e = list[k];
+      uint32_t used = 0;
+      for (int a = 0; a < 3; ++a) {
+        const int32_t v = tri[3 * e + a];
+        if (v >= r0 && v < r1) used |= mask[v - r0];
+      }
+      if (used == 0xFFFFFFFFu) return fail(ctx, HF_ERR_ARG, "more than %d elements share a node", NCOL);
+      const int c = __builtin_ctz(~used);
+      color[k] = c;
+      counts[c]++;
+      P.ncolors = std::max(P.ncolors, c + 1);
+      for (int a = 0; a < 3; ++a) {
+        const int32_t v = tri[3 * e + a];
+        if (v >= r0 && v < r1) mask[v - r0] |= (1u << c);
+      }
+    }
+    const int32_t base = static_cast<int32_t>(P.blk_elist.size());
+    int32_t* cp = &P.blk_cptr[static_cast<size_t>(b) * (NCOL + 1)];
+    cp[0] = base;
+    for (int c = 0; c < NCOL; ++c) cp[c + 1] = cp[c] + counts[c];
+    P.blk_elist.resize(P.blk_elist.size() + list.size());
+    int32_t cur[NCOL];
+    for (int c = 0; c < NCOL; ++c) cur[c] = cp[c];
+    for (size_t k = 0; k < list.size(); ++k) P.blk_elist[cur[color[k]]++] = list[k];
+    P.blk_eptr[b] = base;
+    P.blk_eptr[b + 1] = static_cast<int32_t>(P.blk_elist.size());
+  }
+  // widen every list entry with the offsets of its nine contributions inside the CSR rows
+  P.blk_ent.resize(3 * P.blk_elist.size());
+  for (int b = 0; b < nblk; ++b) {
+    const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
+    for (int32_t q = P.blk_eptr[b]; q < P.blk_eptr[b + 1]; ++q) {
+      const int32_t e = P.blk_elist[q];
+      const int32_t nd[3] = {tri[3 * e], tri[3 * e + 1], tri[3 * e + 2]};
+      uint32_t pos[9] = {0}, owned = 0;
+      for (int a = 0; a < 3; ++a) {
+        if (nd[a] < r0 || nd[a] >= r1) continue;
+        owned |= 1u << a;
+        const int32_t* rb = &P.colidx[P.rowptr[nd[a]]];
+        const int32_t* re = &P.colidx[P.rowptr[nd[a] + 1]];
+        if (re - rb > 255) return fail(ctx, HF_ERR_ARG, "row %d holds more than 255 entries", nd[a]);
+        for (int c = 0; c < 3; ++c) pos[a * 3 + c] = static_cast<uint32_t>(std::lower_bound(rb, re, nd[c]) - rb);
+      }
+      if (tag[e] >= (1 << 21)) return fail(ctx, HF_ERR_ARG, "cell tag %d does not fit the packed list entry (max 2^21 - 1)", tag[e]);
+      const uint32_t w3 = pos[8] | (owned << 8) | (static_cast<uint32_t>(tag[e]) << 11);
+      P.blk_ent[3 * q] = make_int2(nd[0], nd[1]);
+      P.blk_ent[3 * q + 1] = make_int2(nd[2], static_cast<int>(w3));
+      P.blk_ent[3 * q + 2] = make_int2(static_cast<int>(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24)),
+                                       static_cast<int>(pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24)));
+    }
+  }
+  return HF_OK;
+}
+
+size_t spmv_smem_bytes(const hf_ctx* c) { return static_cast<size_t>(c->max_chunk_nnz_s) * 8; }
+
+// LDS-staged element kernel into (Mout, Aout) with the given coefficient tables.
+int launch_assemble_lds(hf_ctx* ctx, bool colored, const double* kappa_tab, const double* rhoc_tab, double dt,
+                        double* Mout, double* Aout) {
+  const int cap = (ctx->max_blk_nnz + 1) & ~1;  // keep the int array 8-byte aligned
+  const size_t sm = static_cast<size_t>(cap) * 16 + (RBA + 1) * 4;
+  if (sm > 64 * 1024) {  // beyond the default dynamic-LDS window: opt in (160 KB per CU on gfx950)
+    HF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_lds<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sm)));
+    HF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_lds<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sm)));
+  }
+  if (colored)
+    hipLaunchKernelGGL(k_assemble_lds<true>, dim3(ctx->nblk_a), dim3(RBA), sm, ctx->stream, ctx->n, cap, ctx->d_rowptr,
+                       ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_zr, kappa_tab, rhoc_tab, dt, Mout, Aout);
+  else
+    hipLaunchKernelGGL(k_assemble_lds<false>, dim3(ctx->nblk_a), dim3(RBA), sm, ctx->stream, ctx->n, cap, ctx->d_rowptr,
+                       ctx->d_blk_eptr, ctx->d_blk_cptr, ctx->d_blk_ent, ctx->d_zr, kappa_tab, rhoc_tab, dt, Mout, Aout);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int launch_assemble(hf_ctx* ctx) {
+  if (ctx->mode == HF_ASM_LDS_COLORED || ctx->mode == HF_ASM_LDS_ATOMIC) {
+    return launch_assemble_lds(ctx, ctx->mode == HF_ASM_LDS_COLORED, ctx->d_kappa, ctx->d_rhoc, ctx->dt, ctx->d_M, ctx->d_A);
+  } else {
+    HF_HIP(hipMemsetAsync(ctx->d_M, 0, sizeof(double) * ctx->nnz, ctx->stream));
+    HF_HIP(hipMemsetAsync(ctx->d_A, 0, sizeof(double) * ctx->nnz, ctx->stream));
+    hipLaunchKernelGGL(k_assemble_global, dim3((ctx->ne + TPB - 1) / TPB), dim3(TPB), 0, ctx->stream, ctx->ne,
+                       ctx->d_rowptr, ctx->d_colidx, ctx->d_elem, ctx->d_zr, ctx->d_kappa, ctx->d_rhoc, ctx->dt,
+                       ctx->d_M, ctx->d_A);
+  }
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+template <int MODE>
+void launch_spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr,
+                 const double* bvec = nullptr, double* pvec = nullptr, double* part1 = nullptr,
+                 double* part2 = nullptr, double w = 0.0, const double* dinv = nullptr, hipEvent_t ev_start = nullptr,
+                 hipEvent_t ev_stop = nullptr, int parity = 0) {
+  // With events: the launch carries them (hipExtLaunchKernelGGL), so they bracket the kernel's own
+  // execution on the device - the same interval rocprofv3 reports - not the launch gap before it.
+  if (ev_start != nullptr)
+    hipExtLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), static_cast<std::uint32_t>(spmv_smem_bytes(c)), c->stream,
+                          ev_start, ev_stop, 0u, c->n, c->nchunks_s, static_cast<int>(TS),
+                          static_cast<const int32_t*>(c->d_rowptr), static_cast<const int32_t*>(c->d_colidx), vals, x, y,
+                          c->d_scal, part0, bvec, dinv ? dinv : static_cast<const double*>(c->d_dinv),
+                          pvec, part1, part2, w, c->P, parity);
+  else
+    hipLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), spmv_smem_bytes(c), c->stream, c->n, c->nchunks_s, TS,
+                       c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, dinv ? dinv : c->d_dinv, pvec, part1,
+                       part2, w, c->P, parity);
+}
+
+constexpr int PROF_PAIRS = 64;
+
+// A linear system on the context's sparsity pattern: values, inverse diagonal, unknown, right-hand side.
+struct LinSys { const double* A; const double* dinv; double* x; const double* b; };
+
+// One Jacobi-PCG iteration = 2 kernels: [convergence, beta, Ap/p by recurrence, p.Ap] + [alpha, x, r, z, r.z, z.z]
+void launch_pcg_iteration(hf_ctx* c, const LinSys& s, int parity) {
+  const bool timed = c->prof && c->prof_used < PROF_PAIRS;
+  hipEvent_t e0 = timed ? c->prof_ev[2 * c->prof_used] : nullptr, e1 = timed ? c->prof_ev[2 * c->prof_used + 1] : nullptr;
+  launch_spmv<9>(c, s.A, c->d_z, c->d_Ap, c->d_part_pAp, nullptr, c->d_p, c->d_part_rz, c->d_part_zz, 0.0, nullptr, e0, e1,
+                 parity);
+  if (timed) c->prof_used++;
+  hipLaunchKernelGGL(k_pcg_update, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
+                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, s.x, c->d_r, c->d_p, c->d_Ap, s.dinv, c->d_z);
+}
+
+}  // namespace

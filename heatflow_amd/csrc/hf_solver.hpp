@@ -1,0 +1,420 @@
+// Part of libheatflow_hip.so (see heatflow_hip.hip): host code - multigrid hierarchy upload, V-cycle, PCG drivers, time step, Dirichlet lifting
+#pragma once
+#include "hf_pattern.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// multigrid: hierarchy upload, V-cycle, AMG-PCG step
+// ------------------------------------------------------------------------------------------
+using DevCsr = hf_ctx::DevCsr;
+using DevLevel = hf_ctx::DevLevel;
+
+void free_dev_csr(DevCsr& m) { dev_free(&m.ptr); dev_free(&m.idx); dev_free(&m.val); m = DevCsr(); }
+
+void drop_graphs(hf_ctx* ctx);
+
+void free_amg(hf_ctx* ctx) {
+  drop_graphs(ctx);
+  for (size_t l = 0; l < ctx->amg.size(); ++l) {
+    DevLevel& L = ctx->amg[l];
+    if (l > 0) { free_dev_csr(L.A); dev_free(&L.dinv); dev_free(&L.x); dev_free(&L.b); }
+    free_dev_csr(L.P); free_dev_csr(L.R);
+    dev_free(&L.x2); dev_free(&L.r);
+  }
+  ctx->amg.clear();
+  dev_free(&ctx->d_coarse_inv);
+  ctx->coarse_n = 0;
+  ctx->amg_ready = false;
+}
+
+int lanes_for(const amg::Csr& m) {
+  const double avg = m.nrow ? static_cast<double>(m.nnz()) / m.nrow : 1.0;
+  return avg <= 4.5 ? 4 : avg <= 9.0 ? 8 : avg <= 18.0 ? 16 : avg <= 36.0 ? 32 : 64;
+}
+
+int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d) {
+  d.nrow = h.nrow; d.ncol = h.ncol; d.nnz = h.nnz(); d.lanes = lanes_for(h);
+  d.rpc = 0;
+  if (h.nrow >= 100000) {  // enough 512-row chunks to fill the chip: LDS-staged kernel, chunk products within 64 KB
+    for (int rpc = TS; rpc >= 32; rpc /= 2) {
+      int mx = 0;
+      for (int r0 = 0; r0 < h.nrow; r0 += rpc) mx = std::max(mx, h.ptr[std::min(h.nrow, r0 + rpc)] - h.ptr[r0]);
+      if (mx <= 8000) { d.rpc = rpc; d.nchunks = (h.nrow + rpc - 1) / rpc; d.chunk_nnz = mx; break; }
+    }
+  }
+  HF_TRY(dev_alloc(ctx, &d.ptr, h.ptr.size()));
+  HF_TRY(dev_alloc(ctx, &d.idx, h.idx.size()));
+  HF_TRY(dev_alloc(ctx, &d.val, h.val.size()));
+  HF_HIP(copy_sync(ctx, d.ptr, h.ptr.data(), sizeof(int32_t) * h.ptr.size(), hipMemcpyHostToDevice));
+  if (!h.idx.empty()) {
+    HF_HIP(copy_sync(ctx, d.idx, h.idx.data(), sizeof(int32_t) * h.idx.size(), hipMemcpyHostToDevice));
+    HF_HIP(copy_sync(ctx, d.val, h.val.data(), sizeof(double) * h.val.size(), hipMemcpyHostToDevice));
+  }
+  return HF_OK;
+}
+
+// Build the hierarchy from the assembled, eliminated fine operator (download -> host set-up -> upload).
+int build_amg(hf_ctx* ctx) {
+  const auto t0 = std::chrono::steady_clock::now();
+  free_amg(ctx);
+  amg::Csr A0;
+  A0.nrow = A0.ncol = ctx->n;
+  A0.ptr.assign(ctx->h_rowptr.begin(), ctx->h_rowptr.end());
+  A0.idx.assign(ctx->h_colidx.begin(), ctx->h_colidx.end());
+  A0.val.resize(ctx->nnz);
+  HF_HIP(copy_sync(ctx, A0.val.data(), ctx->d_A, sizeof(double) * ctx->nnz, hipMemcpyDeviceToHost));
+  amg::Hierarchy H;
+  amg::Params prm;
+  if (const char* e = std::getenv("HEATFLOW_AMG_THETA")) prm.theta = std::atof(e);          // tuning knobs
+  if (const char* e = std::getenv("HEATFLOW_AMG_COARSE")) prm.coarse_size = std::atoi(e);
+  if (const char* e = std::getenv("HEATFLOW_AMG_SMOOTH_SCALE")) prm.smooth_scale = std::atof(e);
+  if (!amg::build(std::move(A0), prm, H)) return fail(ctx, HF_ERR_STATE, "AMG set-up failed (non-positive diagonal or singular coarse operator)");
+  const size_t nl = H.levels.size();
+  ctx->amg.resize(nl);
+  for (size_t l = 0; l < nl; ++l) {
+    DevLevel& L = ctx->amg[l];
+    const amg::Level& hl = H.levels[l];
+    L.n = static_cast<int>(hl.dinv.size());
+    L.omega = hl.omega;
+    if (l == 0) {
+      L.A.nrow = L.A.ncol = ctx->n; L.A.nnz = ctx->nnz; L.A.ptr = ctx->d_rowptr; L.A.idx = ctx->d_colidx; L.A.val = ctx->d_A;
+      L.dinv = ctx->d_dinv;
+    } else {
+      HF_TRY(upload_csr(ctx, hl.A, L.A));
+      HF_TRY(dev_alloc(ctx, &L.dinv, L.n));
+      HF_HIP(copy_sync(ctx, L.dinv, hl.dinv.data(), sizeof(double) * L.n, hipMemcpyHostToDevice));
+      HF_TRY(dev_alloc(ctx, &L.x, L.n + 2));
+      HF_TRY(dev_alloc(ctx, &L.b, L.n + 2));
+      HF_TRY(dev_alloc(ctx, &L.x2, L.n + 2));
+      HF_TRY(dev_alloc(ctx, &L.r, L.n + 2));
+      HF_HIP(hipMemsetAsync(L.b, 0, sizeof(double) * (L.n + 2), ctx->stream));   // the dense solve reads b in pairs
+    }
+    if (l + 1 < nl) { HF_TRY(upload_csr(ctx, hl.P, L.P)); HF_TRY(upload_csr(ctx, hl.R, L.R)); }
+  }
+  // coarsest level: dense inverse by Gauss-Jordan on the device
+  ctx->coarse_n = 0;
+  if (nl > 1 && H.coarse_n > 0 && H.coarse_n <= 4096) {
+    const int nc = H.coarse_n;
+    const int ld = (nc + 1) & ~1;
+    const amg::Csr& Ac = H.levels.back().A;
+    std::vector<double> dense(static_cast<size_t>(nc) * nc, 0.0), eye(static_cast<size_t>(nc) * nc, 0.0);
+    for (int i = 0; i < nc; ++i) {
+      for (int k = Ac.ptr[i]; k < Ac.ptr[i + 1]; ++k) dense[static_cast<size_t>(i) * nc + Ac.idx[k]] = Ac.val[k];
+      eye[static_cast<size_t>(i) * nc + i] = 1.0;
+    }
+    DevTemp<double> t_dense, t_inv, t_prow, t_pcol;
+    double *&d_dense = t_dense.p, *&d_inv = t_inv.p, *&d_prow = t_prow.p, *&d_pcol = t_pcol.p;
+    HF_TRY(dev_alloc(ctx, &d_dense, dense.size()));
+    HF_TRY(dev_alloc(ctx, &d_inv, eye.size()));
+    HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv, static_cast<size_t>(nc) * ld));
+    HF_TRY(dev_alloc(ctx, &d_prow, 2 * static_cast<size_t>(nc)));
+    HF_TRY(dev_alloc(ctx, &d_pcol, static_cast<size_t>(nc)));
+    HF_HIP(copy_sync(ctx, d_dense, dense.data(), sizeof(double) * dense.size(), hipMemcpyHostToDevice));
+    HF_HIP(copy_sync(ctx, d_inv, eye.data(), sizeof(double) * eye.size(), hipMemcpyHostToDevice));
+    const int gp = std::max(1, (nc + TPB - 1) / TPB);
+    const int ge = static_cast<int>(std::min<size_t>((static_cast<size_t>(nc) * nc + TPB - 1) / TPB, 4096));
+    for (int cpiv = 0; cpiv < nc; ++cpiv) {
+      hipLaunchKernelGGL(k_gj_pivot, dim3(gp), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, d_inv, d_prow, d_pcol);
+      hipLaunchKernelGGL(k_gj_elim, dim3(ge), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, d_inv, d_prow, d_pcol);
+    }
+    HF_HIP(hipGetLastError());
+    // rows re-pitched to the even leading dimension (zero pad column)
+    HF_HIP(hipMemsetAsync(ctx->d_coarse_inv, 0, sizeof(double) * nc * ld, ctx->stream));
+    HF_HIP(hipMemcpy2DAsync(ctx->d_coarse_inv, sizeof(double) * ld, d_inv, sizeof(double) * nc, sizeof(double) * nc, nc,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->coarse_ld = ld;
+    ctx->coarse_n = nc;
+  }
+  ctx->amg_opc = H.op_complexity;
+  ctx->amg_ready = true;
+  ctx->amg_setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return HF_OK;
+}
+
+// VMODE 0: y = A x, 1: y += A x, 2: y = b - A x, 3: y = x + w D^-1 (b - A x); LDS-staged kernel when the
+// matrix is big enough to fill the chip, sub-wave kernel otherwise.
+template <int VMODE>
+void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y, const double* b = nullptr,
+                const double* dinv = nullptr, double w = 0.0, double* xout = nullptr) {
+  if (m.rpc > 0) {
+    constexpr int SM = VMODE == 0 ? 0 : VMODE == 1 ? 6 : VMODE == 2 ? 3 : VMODE == 3 ? 4 : 7;
+    int grid = std::min(m.nchunks, MAXP);
+    if (grid >= 64) grid &= ~7;
+    hipLaunchKernelGGL(k_spmv<SM>, dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream, m.nrow,
+                       m.nchunks, m.rpc, m.ptr, m.idx, m.val, x, y, c->d_scal, static_cast<double*>(nullptr), b, dinv,
+                       xout, static_cast<double*>(nullptr), static_cast<double*>(nullptr), w, 0, 0);
+    return;
+  }
+  const int lanes = m.lanes;
+  const long long threads = static_cast<long long>(m.nrow) * lanes;
+  const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 2048)));
+#define HF_VEC(L) hipLaunchKernelGGL((k_spmv_vec<L, VMODE>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, m.val, x, y, b, dinv, w, c->d_scal, xout)
+  switch (lanes) {
+    case 4: HF_VEC(4); break;
+    case 8: HF_VEC(8); break;
+    case 16: HF_VEC(16); break;
+    case 32: HF_VEC(32); break;
+    default: HF_VEC(64); break;
+  }
+#undef HF_VEC
+}
+
+// z = B r: one V(1,1) cycle.  Fixed buffer roles (no pointer swaps, so captured graphs and eager
+// launches always agree): on entry d_z holds w0 D^-1 r (written by the update / start kernel); on exit
+// d_z2 holds z and part_rz[out_slot] the partials of r.z.  On every coarser level x carries the
+// pre-smoothed iterate plus the coarse correction and x2 the post-smoothed result (the coarsest
+// level's result is its x).
+void vcycle(hf_ctx* c, int out_slot) {
+  const int nl = static_cast<int>(c->amg.size());
+  DevLevel& L0 = c->amg[0];
+  if (nl == 1) {  // no coarse level: one more Jacobi sweep keeps the operator symmetric
+    launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
+    return;
+  }
+  launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r);                 // t = r - A z
+  launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);                                // b1 = R0 t
+  for (int l = 1; l + 1 < nl; ++l) {
+    DevLevel& L = c->amg[l];
+    launch_vec<4>(c, L.A, L.b, L.r, L.b, L.dinv, L.omega, L.x);                 // x_l = w D^-1 b_l ; r_l = b_l - A_l x_l
+    launch_vec<0>(c, L.R, L.r, c->amg[l + 1].b);                                // b_{l+1} = R_l r_l
+  }
+  {
+    DevLevel& Lc = c->amg[nl - 1];
+    if (c->coarse_n > 0) {
+      const int g = std::max(1, std::min((Lc.n + 1) / 2, 2048));
+      hipLaunchKernelGGL(k_dense_mv, dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv, Lc.b, Lc.x,
+                         c->d_scal);
+    } else {
+      const int g = std::max(1, std::min((Lc.n + TPB - 1) / TPB, 1024));
+      hipLaunchKernelGGL(k_scale, dim3(g), dim3(TPB), 0, c->stream, Lc.n, Lc.omega, Lc.dinv, Lc.b, Lc.x, c->d_scal);
+    }
+  }
+  for (int l = nl - 2; l >= 1; --l) {
+    DevLevel& L = c->amg[l];
+    const double* coarse = (l + 1 == nl - 1) ? c->amg[l + 1].x : c->amg[l + 1].x2;
+    launch_vec<1>(c, L.P, coarse, L.x);                                         // x_l += P_l x_{l+1}
+    launch_vec<3>(c, L.A, L.x, L.x2, L.b, L.dinv, L.omega);                     // post-smooth -> x2
+  }
+  launch_vec<1>(c, L0.P, (nl == 2) ? c->amg[1].x : c->amg[1].x2, c->d_z);       // z += P0 x_1
+  launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
+}
+
+// One multigrid-PCG iteration: iteration head (as above), update (alpha, x, r, z0 = w D^-1 r), V-cycle (z, r.z)
+void launch_amg_iteration(hf_ctx* c, int parity) {
+  const bool timed = c->prof && c->prof_used < PROF_PAIRS;
+  hipEvent_t e0 = timed ? c->prof_ev[2 * c->prof_used] : nullptr, e1 = timed ? c->prof_ev[2 * c->prof_used + 1] : nullptr;
+  launch_spmv<9>(c, c->d_A, c->d_z2, c->d_Ap, c->d_part_pAp, nullptr, c->d_p, c->d_part_rz, c->d_part_zz, 0.0, nullptr, e0,
+                 e1, parity);
+  if (timed) c->prof_used++;
+  hipLaunchKernelGGL(k_pcg_update_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
+                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, c->d_u, c->d_r, c->d_p, c->d_Ap, c->d_dinv,
+                     c->amg[0].omega, c->d_z);
+  vcycle(c, parity ^ 1);
+}
+
+int read_scal(hf_ctx* ctx) {
+  HF_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->prof) {  // harvest the event pairs of this burst (only launches that really ran count)
+    for (int k = 0; k < ctx->prof_used; ++k) {
+      float ms = 0.f;
+      const bool ran = !ctx->h_scal->done || (ctx->prof_base + k) < ctx->h_scal->iters;
+      if (ran && hipEventElapsedTime(&ms, ctx->prof_ev[2 * k], ctx->prof_ev[2 * k + 1]) == hipSuccess) {
+        ctx->prof_spmv_ms += ms;
+        ctx->prof_spmv_n += 1;
+      }
+    }
+    ctx->prof_used = 0;
+  }
+  return HF_OK;
+}
+
+void drop_graphs(hf_ctx* ctx) {
+  for (auto& g : ctx->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  ctx->graphs.clear();
+}
+
+// Executable graph holding `iters` (even) consecutive iterations of the loop for `sys`; captured on
+// first use, replayed afterwards.  Returns nullptr when capture is unavailable (the caller then
+// launches eagerly).
+hipGraphExec_t iteration_graph(hf_ctx* ctx, const LinSys& sys, bool use_amg, int iters) {
+  for (auto& g : ctx->graphs)
+    if (g.A == sys.A && g.dinv == sys.dinv && g.x == sys.x && g.b == sys.b && g.amg == use_amg && g.iters == iters)
+      return g.exec;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  const bool dbg = std::getenv("HEATFLOW_DEBUG") != nullptr;
+  if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    if (dbg) fprintf(stderr, "[heatflow] graph capture could not start\n");
+    return nullptr;
+  }
+  for (int k = 0; k < iters; ++k) {
+    if (use_amg) launch_amg_iteration(ctx, k & 1);
+    else launch_pcg_iteration(ctx, sys, k & 1);
+  }
+  if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || graph == nullptr) {
+    if (dbg) fprintf(stderr, "[heatflow] graph capture failed\n");
+    return nullptr;
+  }
+  const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  size_t nnodes = 0;
+  (void)hipGraphGetNodes(graph, nullptr, &nnodes);
+  (void)hipGraphDestroy(graph);
+  if (dbg) fprintf(stderr, "[heatflow] graph of %d iterations: %zu nodes, instantiate %s\n", iters, nnodes, hipGetErrorString(e));
+  if (e != hipSuccess) return nullptr;
+  ctx->graphs.push_back({sys.A, sys.dinv, sys.x, sys.b, use_amg, iters, exec});
+  return exec;
+}
+
+// PCG on `sys` started from sys.x.  Jacobi: any system on the pattern; AMG: the main system only.
+// Iteration count / residual are left in h_scal; *pred carries the burst-size hint between calls.
+int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double atol, int max_it, int* pred) {
+  if (!use_amg) {
+    // r = b - A x, z = D^-1 r, r.z
+    launch_spmv<2>(ctx, sys.A, sys.x, ctx->d_r, ctx->d_part_rz, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn, 0.0,
+                   sys.dinv);
+    hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
+                       ctx->d_part_bn, ctx->d_scal);
+  } else {
+    // r = b - A x, z0 = w D^-1 r; tolerance; z = B r (V-cycle, r.z into slot 0)
+    HF_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(Scal), ctx->stream));   // done = 0 so the start kernels run
+    launch_spmv<5>(ctx, sys.A, sys.x, ctx->d_r, nullptr, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn,
+                   ctx->amg[0].omega);
+    hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
+                       ctx->d_part_bn, ctx->d_scal);
+    vcycle(ctx, 0);
+  }
+  HF_HIP(hipGetLastError());
+
+  int launched = 0;
+  if (*pred <= 0) {  // previous solve needed no iteration (e.g. constant field): look before launching
+    HF_TRY(read_scal(ctx));
+    if (ctx->h_scal->done == 1) return HF_OK;
+  }
+  // first burst: what the previous solve needed (the counts drift slowly), then check in small bursts
+  int burst = std::max(2, std::min(max_it, *pred > 0 ? *pred : (use_amg ? 8 : 32)));
+  // graph unit: 2 multigrid iterations (~40 kernels) or 16 Jacobi iterations (48 kernels) per replay
+  const int unit = use_amg ? 2 : 16;
+  hipGraphExec_t gexec = (ctx->use_graph && !ctx->prof) ? iteration_graph(ctx, sys, use_amg, unit) : nullptr;
+  while (true) {
+    burst += burst & 1;  // parity pairs
+    ctx->prof_base = launched;
+    if (gexec != nullptr) {
+      burst = ((burst + unit - 1) / unit) * unit;
+      for (int k = 0; k < burst; k += unit) HF_HIP(hipGraphLaunch(gexec, ctx->stream));
+    } else {
+      for (int k = 0; k < burst; ++k) {
+        if (use_amg) launch_amg_iteration(ctx, (launched + k) & 1);
+        else launch_pcg_iteration(ctx, sys, (launched + k) & 1);
+      }
+    }
+    launched += burst;
+    HF_HIP(hipGetLastError());
+    HF_TRY(read_scal(ctx));
+    if (ctx->h_scal->done) break;
+    if (launched >= max_it) break;
+    burst = std::min(std::max(use_amg ? 2 : 8, launched / 8), max_it - launched);
+    burst = std::max(burst, 2);
+  }
+  *pred = ctx->h_scal->iters;
+  if (ctx->h_scal->done == 2) return fail(ctx, HF_ERR_NOCONV, "PCG breakdown (p.Ap <= 0) after %d iterations", ctx->h_scal->iters);
+  if (!ctx->h_scal->done)
+    return fail(ctx, HF_ERR_NOCONV, "PCG not converged in %d iterations (rel. residual %.3e)", ctx->h_scal->iters,
+                std::sqrt(ctx->h_scal->zz / std::max(ctx->h_scal->bn2, 1e-300)));
+  return HF_OK;
+}
+
+// One time step with g already in d_g.  Leaves iteration count / residual in h_scal.
+int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
+  const int nb = ctx->nbc;
+  // b = M u^n   (assemble_vector, run_with_diamond.py:476); with a previous step available the same
+  // pass writes the extrapolated start vector 2 u^n - u^{n-1}, and the three state buffers rotate
+  if (ctx->extrapolate && ctx->have_prev) {
+    launch_spmv<8>(ctx, ctx->d_M, ctx->d_u, ctx->d_b, nullptr, ctx->d_uprev, ctx->d_ustart);
+    // u^{n-1} <- u^n, iterate <- start vector (copies, not pointer rotation: captured graphs hold d_u)
+    HF_HIP(hipMemcpyAsync(ctx->d_uprev, ctx->d_u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+    HF_HIP(hipMemcpyAsync(ctx->d_u, ctx->d_ustart, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    launch_spmv<0>(ctx, ctx->d_M, ctx->d_u, ctx->d_b);
+    if (ctx->extrapolate) {         // keep u^n for the next step
+      HF_HIP(hipMemcpyAsync(ctx->d_uprev, ctx->d_u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+      ctx->have_prev = true;
+    }
+  }
+  if (nb > 0) {
+    if (ctx->nlift_rows > 0)  // apply_lifting (:477)
+      hipLaunchKernelGGL(k_lift, dim3((ctx->nlift_rows + 255) / 256), dim3(256), 0, ctx->stream, ctx->nlift_rows,
+                         ctx->d_lift_rows, ctx->d_lift_ptr, ctx->d_lift_bc, ctx->d_lift_val, ctx->d_g, ctx->d_b);
+    // set_bc (:479); the same values seed the iterate
+    hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, ctx->d_g,
+                       ctx->d_b, ctx->d_u);
+  }
+  const LinSys sys{ctx->d_A, ctx->d_dinv, ctx->d_u, ctx->d_b};
+  const bool use_amg = ctx->precond == 1 && ctx->amg_ready;
+  int rc = pcg_solve(ctx, sys, use_amg, rtol, atol, max_it, &ctx->pred_iters);
+  if (rc == HF_ERR_NOCONV && use_amg && ctx->h_scal->done == 2) {
+    // breakdown inside the multigrid-preconditioned loop (p.Ap <= 0: the preconditioner was not SPD for
+    // this operator): finish the step with the Jacobi preconditioner from the current iterate - still on
+    // the GPU - and count the event
+    ctx->amg_fallbacks += 1;
+    int pred = 0;
+    rc = pcg_solve(ctx, sys, false, rtol, atol, max_it, &pred);
+  }
+  return rc;
+}
+
+int ensure_samples(hf_ctx* ctx, int ns) {
+  if (ns <= ctx->samp_cap) return HF_OK;
+  HF_TRY(dev_alloc(ctx, &ctx->d_samp_idx, ns));
+  HF_TRY(dev_alloc(ctx, &ctx->d_samp, ns));
+  ctx->samp_cap = ns;
+  return HF_OK;
+}
+
+int build_lift(hf_ctx* ctx) {
+  // Host: for every free row i and BC column j with A_ij in the pattern -> (row i, bc index of j, slot)
+  const int32_t n = ctx->n, nbc = ctx->nbc;
+  std::vector<int32_t> dofs(nbc);
+  HF_HIP(copy_sync(ctx, dofs.data(), ctx->d_bc_dofs, sizeof(int32_t) * nbc, hipMemcpyDeviceToHost));
+  std::vector<int32_t> bc_index(n, -1);
+  for (int32_t q = 0; q < nbc; ++q) bc_index[dofs[q]] = q;
+  // free rows adjacent to a BC dof = columns of the BC rows (pattern is symmetric)
+  std::vector<int32_t> rows;
+  for (int32_t q = 0; q < nbc; ++q) {
+    const int32_t j = dofs[q];
+    for (int32_t k = ctx->h_rowptr[j]; k < ctx->h_rowptr[j + 1]; ++k) {
+      const int32_t i = ctx->h_colidx[k];
+      if (bc_index[i] < 0) rows.push_back(i);
+    }
+  }
+  std::sort(rows.begin(), rows.end());
+  rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+  std::vector<int32_t> ptr(rows.size() + 1, 0), lbc, lslot;
+  for (size_t r = 0; r < rows.size(); ++r) {
+    const int32_t i = rows[r];
+    for (int32_t k = ctx->h_rowptr[i]; k < ctx->h_rowptr[i + 1]; ++k) {
+      const int32_t q = bc_index[ctx->h_colidx[k]];
+      if (q >= 0) { lbc.push_back(q); lslot.push_back(k); }
+    }
+    ptr[r + 1] = static_cast<int32_t>(lbc.size());
+  }
+  ctx->nlift_rows = static_cast<int32_t>(rows.size());
+  ctx->nlift = static_cast<int32_t>(lbc.size());
+  HF_TRY(dev_alloc(ctx, &ctx->d_lift_rows, rows.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_lift_ptr, ptr.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_lift_bc, lbc.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_lift_slot, lslot.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_lift_val, lbc.size()));
+  if (!rows.empty()) HF_HIP(copy_sync(ctx, ctx->d_lift_rows, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_lift_ptr, ptr.data(), sizeof(int32_t) * ptr.size(), hipMemcpyHostToDevice));
+  if (!lbc.empty()) {
+    HF_HIP(copy_sync(ctx, ctx->d_lift_bc, lbc.data(), sizeof(int32_t) * lbc.size(), hipMemcpyHostToDevice));
+    HF_HIP(copy_sync(ctx, ctx->d_lift_slot, lslot.data(), sizeof(int32_t) * lslot.size(), hipMemcpyHostToDevice));
+  }
+  return HF_OK;
+}
+
+}  // namespace

@@ -45,8 +45,9 @@ def build_library(force=False, verbose=False):
     src = os.path.join(_HERE, "csrc", "heatflow_hip.hip")
     hdr = os.path.join(_HERE, "..", "include", "heatflow_hip.h")
     if not force and os.path.isfile(LIB_PATH):
-        newest = max(os.path.getmtime(src), os.path.getmtime(hdr),
-                     os.path.getmtime(os.path.join(_HERE, "csrc", "amg_host.hpp")))
+        csrc = os.path.join(_HERE, "csrc")
+        newest = max([os.path.getmtime(src), os.path.getmtime(hdr)] +
+                     [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith(".hpp")])
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "libheatflow_hip.so"]

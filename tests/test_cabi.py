@@ -52,7 +52,7 @@ def test_product_code_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "heatflow_amd")
     for dirpath, _, files in os.walk(pkg):
         for fn in files:
-            if fn.endswith((".py", ".hip", ".h")):
+            if fn.endswith((".py", ".hip", ".h", ".hpp")):
                 with open(os.path.join(dirpath, fn)) as f:
                     src = f.read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{fn} imports the oracle"
