@@ -206,9 +206,10 @@ class SimulationSession:
         nodes = nearest_nodes(self.coords, coords_w) if names else None
 
         flux = FluxSampler(self.coords) if read_flux else None
-        if flux is not None:
+        if flux is not None and not getattr(prob, "_flux_ready", False):
             print("Setting up radial heat flux sampling...")
-            prob.backend.flux_setup()
+            prob.backend.flux_setup()          # once per mesh: the unit-coefficient mass matrix does not depend on kappa
+            prob._flux_ready = True
         print("Beginning loop...")
         t_loop = time.time()
         if field_sink is None and flux is None:
