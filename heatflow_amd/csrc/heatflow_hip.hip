@@ -180,6 +180,23 @@ int hf_set_materials(hf_ctx* ctx, int32_t n_mat, const int32_t* tags, const doub
   return HF_OK;
 }
 
+int hf_update_kappa(hf_ctx* ctx, int32_t n_mat, const int32_t* tags, const double* kappa) {
+  if (!ctx) return HF_ERR_ARG;
+  if (!ctx->have_mat || !ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_update_kappa needs a completed hf_assemble first");
+  if (n_mat <= 0 || !tags || !kappa) return fail(ctx, HF_ERR_ARG, "hf_update_kappa: bad arguments");
+  HF_HIP(hipSetDevice(ctx->dev));
+  std::vector<double> tk(ctx->tab_len);
+  HF_HIP(copy_sync(ctx, tk.data(), ctx->d_kappa, sizeof(double) * ctx->tab_len, hipMemcpyDeviceToHost));
+  for (int32_t i = 0; i < n_mat; ++i) {
+    if (tags[i] < 0 || tags[i] >= ctx->tab_len || !ctx->h_tag_used[tags[i]])
+      return fail(ctx, HF_ERR_ARG, "hf_update_kappa: tag %d is not a cell tag of the mesh", tags[i]);
+    if (!(kappa[i] > 0.0)) return fail(ctx, HF_ERR_ARG, "hf_update_kappa: kappa must be positive");
+    tk[tags[i]] = kappa[i];
+  }
+  HF_HIP(copy_sync(ctx, ctx->d_kappa, tk.data(), sizeof(double) * ctx->tab_len, hipMemcpyHostToDevice));
+  return hf_assemble(ctx, ctx->dt, ctx->mode);
+}
+
 int hf_set_dirichlet(hf_ctx* ctx, int32_t n_bc, const int32_t* dofs) {
   if (!ctx) return HF_ERR_ARG;
   if (!ctx->have_mesh) return fail(ctx, HF_ERR_STATE, "hf_set_dirichlet before hf_set_mesh");

@@ -21,7 +21,7 @@ K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS = range(6)
 
 EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_materials",
-    "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
+    "hf_update_kappa", "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
     "hf_flux_setup", "hf_flux_project", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
 
@@ -83,6 +83,7 @@ def load_library():
         "hf_destroy": [vp],
         "hf_set_mesh": [vp, i32, i32, pd, pi, pi],
         "hf_set_materials": [vp, i32, pi, pd, pd],
+        "hf_update_kappa": [vp, i32, pi, pd],
         "hf_set_dirichlet": [vp, i32, pi],
         "hf_assemble": [vp, dbl, i32],
         "hf_set_precond": [vp, i32, i32],
@@ -189,6 +190,11 @@ class HeatflowHIP:
         if not (t.shape == k.shape == c.shape) or t.ndim != 1:
             raise ValueError("set_materials: three 1-D arrays of equal length expected")
         self._check(self._lib.hf_set_materials(self._ctx, len(t), _pi(t), _pd(k), _pd(c)))
+
+    def update_kappa(self, tags, kappa):
+        """Overwrite the conductivity of some cell tags and re-assemble (kappa sweeps)."""
+        t, k = _i32(tags), _f64(kappa)
+        self._check(self._lib.hf_update_kappa(self._ctx, len(t), _pi(t), _pd(k)))
 
     def set_dirichlet(self, dofs):
         d = _i32(dofs)

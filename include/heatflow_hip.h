@@ -86,6 +86,11 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t n_e, const double* zr, const int
  * tag == tags[i].  May be called again (kappa sweep) followed by hf_assemble. */
 int hf_set_materials(hf_ctx* ctx, int32_t n_mat, const int32_t* tags, const double* kappa, const double* rho_c);
 
+/* Kappa sweep step: overwrite the conductivity of the listed cell tags (rho_c, mesh, pattern, Dirichlet
+ * set, dt and assembly mode stay) and re-value M, A, D^-1 - i.e. hf_set_materials + hf_assemble for the
+ * entries that changed (reference: a new run_simulation per kappa, sweep_test.py:55-75). */
+int hf_update_kappa(hf_ctx* ctx, int32_t n_mat, const int32_t* tags, const double* kappa);
+
 /* Dirichlet DOFs (unique; the host resolves overlaps "later BC wins" beforehand).
  * The order defines the order of g_bc in hf_step.  n_bc = 0 removes all BCs. */
 int hf_set_dirichlet(hf_ctx* ctx, int32_t n_bc, const int32_t* dofs);

@@ -158,10 +158,9 @@ def test_kappa_update_reuses_pattern(hip, case_with_diamond_small):
     import copy
     prob = make_problem(cfg, stack, mesh)
     try:
-        tag_to_k, tag_to_rc = material_tables(stack, mesh)
-        tag_to_k = dict(tag_to_k)
-        tag_to_k[mesh.material_tags["p_sample"]] = 4.4
-        prob.set_materials(tag_to_k, tag_to_rc)
+        prob.backend.update_kappa([mesh.material_tags["p_sample"]], [4.4])      # hf_update_kappa
+        with pytest.raises(ValueError):
+            prob.backend.update_kappa([77], [1.0])                               # not a cell tag of this mesh
         cfg2 = copy.deepcopy(cfg)
         cfg2["mats"]["p_sample"]["k"] = 4.4
         ref = oracle_run(cfg2, mesh, 10)
