@@ -232,3 +232,37 @@ def test_msh41_ascii_reader(tmp_path):
     bad.write_text("$MeshFormat\n4.1 1 8\n$EndMeshFormat\n")
     with pytest.raises(MeshError, match="binary"):
         read_msh(str(bad))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_mesher_on_random_layer_stacks(seed):
+    """Random touching-rectangle stacks (thin and thick layers, mesh sizes spread over 2.5 decades,
+    an L-shaped union): conforming, every triangle inside its box, sizes honoured, areas add up."""
+    rng = np.random.default_rng(seed)
+    nlay = int(rng.integers(2, 6))
+    thick = 10.0 ** rng.uniform(-7.5, -5.0, nlay)
+    z = np.concatenate([[0.0], np.cumsum(thick)]) - 1e-6
+    r_in = float(10.0 ** rng.uniform(-6, -5))
+    mats = [Material(f"l{k}", [z[k], z[k + 1], 0.0, r_in], {"k": 1.0, "rho_cv": 1.0},
+                     float(thick[k] / rng.uniform(1.5, 12.0))) for k in range(nlay)]
+    if seed % 2 == 0:                       # an outer ring around all layers, coarse
+        mats.append(Material("ring", [z[0], z[-1], r_in, r_in * rng.uniform(1.5, 4.0)], {"k": 1.0, "rho_cv": 1.0},
+                             float(max(m.mesh_size for m in mats) * rng.uniform(2.0, 30.0))))
+    mesh = Mesh("m", [z[0], z[-1], 0.0, max(m.boundaries[3] for m in mats)], mats).build_mesh()
+    c, t = mesh.coords, mesh.tris
+    p0, p1, p2 = c[t[:, 0]], c[t[:, 1]], c[t[:, 2]]
+    area = 0.5 * ((p1[:, 0] - p0[:, 0]) * (p2[:, 1] - p0[:, 1]) - (p2[:, 0] - p0[:, 0]) * (p1[:, 1] - p0[:, 1]))
+    assert (area > 0).all()
+    assert area.sum() == pytest.approx(sum((m.boundaries[1] - m.boundaries[0]) * (m.boundaries[3] - m.boundaries[2])
+                                           for m in mats), rel=1e-11)
+    uniq, cnt = np.unique(_edges(t), axis=0, return_counts=True)
+    assert set(cnt.tolist()) <= {1, 2}
+    assert len(np.unique(t)) == len(c)
+    cen = (p0 + p1 + p2) / 3
+    for k, m in enumerate(mats):
+        sel = mesh.tags == k + 1
+        b = m.boundaries
+        assert sel.any() and ((cen[sel, 0] > b[0]) & (cen[sel, 0] < b[1]) & (cen[sel, 1] > b[2]) & (cen[sel, 1] < b[3])).all()
+        legs = np.sort(np.stack([np.linalg.norm(p1 - p0, axis=1), np.linalg.norm(p2 - p1, axis=1),
+                                 np.linalg.norm(p0 - p2, axis=1)], axis=1)[sel], axis=1)
+        assert legs[:, 1].max() <= m.mesh_size * (1 + 1e-9)
