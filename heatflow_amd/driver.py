@@ -35,7 +35,7 @@ from .bc import P1Space, RowDirichletBC
 from .geometry import stack_no_diamond, stack_with_diamond
 from .heating import HeatingCurve
 from .mesh import Mesh, load_mesh_arrays
-from .solver import DEFAULT_MAX_IT, DEFAULT_RTOL, HeatProblem, nearest_nodes
+from .solver import DEFAULT_MAX_IT, DEFAULT_RTOL, HeatProblem
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -132,6 +132,7 @@ class SimulationSession:
         self.precond = precond           # 1 = multigrid-preconditioned CG (default), 0 = Jacobi-PCG
         self.problem = None
         self._key = None
+        self._tree = None
 
     def close(self):
         if self.problem is not None:
@@ -203,7 +204,13 @@ class SimulationSession:
         prob = self.problem
 
         names, coords_w = _parse_watchers(watcher_points)
-        nodes = nearest_nodes(self.coords, coords_w) if names else None
+        if names:
+            if self._tree is None:                      # nearest-node lookup structure: once per resident mesh
+                from scipy.spatial import cKDTree
+                self._tree = cKDTree(self.coords)
+            nodes = np.array([self._tree.query(p)[1] for p in coords_w], dtype=np.int32)
+        else:
+            nodes = None
 
         flux = FluxSampler(self.coords) if read_flux else None
         if flux is not None and not getattr(prob, "_flux_ready", False):
