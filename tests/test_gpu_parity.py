@@ -512,3 +512,59 @@ def test_two_sided_heating_extension_matches_oracle(hip, tmp_path):
     one_sided = ho.run_reference_algorithm(cfg, coords, tris, tags, mtags, HEATING_CSV, keep_fields=True)
     assert np.abs(ref["fields"][-1] - one_sided["fields"][-1]).max() > 0.5        # the second line matters
     assert os.path.isfile(os.path.join(out, "radial_gradient.csv"))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_general_triangles_random_meshes(hip, seed):
+    """gmsh meshes hold arbitrary triangles, the built-in mesher only right ones: jittered nodes, mixed
+    orientations (CW and CCW), random tags / coefficients / Dirichlet sets, r starting at 0 or off the
+    axis.  Matrices, three time steps (both preconditioners) and the gradient projection vs the oracle."""
+    from oracle import heat_oracle as ho
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(100 + seed)
+    nz, nr = int(rng.integers(9, 30)), int(rng.integers(9, 30))
+    coords, tris = _unit_square_mesh(nz, nr)
+    hz, hr = 1.0e-6 / nz, 2.0e-6 / nr
+    inner = (coords[:, 0] > 0) & (coords[:, 0] < 1.0e-6) & (coords[:, 1] > 0) & (coords[:, 1] < 2.0e-6)
+    coords = coords.copy()
+    coords[inner, 0] += rng.uniform(-0.3, 0.3, inner.sum()) * hz
+    coords[inner, 1] += rng.uniform(-0.3, 0.3, inner.sum()) * hr
+    if seed == 1:
+        coords[:, 1] += 0.7e-6                                       # annulus: no node on the axis
+    flip = rng.random(len(tris)) < 0.5
+    tris = tris.copy()
+    tris[flip] = tris[flip][:, [0, 2, 1]]                            # clockwise elements
+    tris = tris[rng.permutation(len(tris))]                          # no ordering assumption
+    tags = rng.integers(1, 5, len(tris)).astype(np.int32)
+    tag_to_k = {t: float(10.0 ** rng.uniform(0, 3)) for t in range(1, 5)}
+    tag_to_rc = {t: float(10.0 ** rng.uniform(5.5, 7)) for t in range(1, 5)}
+    dt = 3e-9
+    bc_dofs = np.sort(rng.choice(len(coords), size=int(rng.integers(1, 40)), replace=False)).astype(np.int32)
+    u0 = 300.0 + 100.0 * rng.random(len(coords))
+    g_fn = lambda t: 300.0 + 1e10 * t + 50.0 * np.sin(np.arange(len(bc_dofs)))
+    sol = ho.OracleSolver(coords, tris, tags, tag_to_k, tag_to_rc, dt,
+                          [{"dofs": bc_dofs, "value": lambda r, t: g_fn(t)}], u0)
+    refs = [sol.step((k + 1) * dt).copy() for k in range(3)]
+    proj = ho.GradientProjector(coords, tris)
+    for precond in (0, 1):
+        with hip.HeatflowHIP(0) as be:
+            be.set_mesh(coords, tris, tags)
+            tl = sorted(tag_to_k)
+            be.set_materials(tl, [tag_to_k[t] for t in tl], [tag_to_rc[t] for t in tl])
+            be.set_dirichlet(bc_dofs)
+            be.set_precond(precond)
+            be.assemble(dt, hip.ASM_LDS_ATOMIC if precond else hip.ASM_LDS_COLORED)
+            rowptr, colidx, A, M = be.get_csr()
+            assert _rel_row_err(A, csr_values_on_pattern(sol.Ahat, rowptr, colidx), rowptr) < 1e-12
+            assert _rel_row_err(M, csr_values_on_pattern(sol.M, rowptr, colidx), rowptr) < 1e-12
+            be.set_state(u0)
+            for k in range(3):
+                be.step(g_fn((k + 1) * dt), rtol=1e-12)
+                assert np.abs(be.get_state() - refs[k]).max() <= 1e-6
+            be.flux_setup()
+            be.set_state(refs[2])
+            gz, gr = be.flux_project(rtol=1e-12)
+            g_ref = proj.project(refs[2])
+            scale = np.abs(g_ref).max()
+            assert np.abs(gz - g_ref[:, 0]).max() <= 1e-8 * scale and np.abs(gr - g_ref[:, 1]).max() <= 1e-8 * scale

@@ -8,7 +8,7 @@ import yaml
 from conftest import ROOT, build_case, load_cfg
 from heatflow_amd.geometry import build_stack, scale_mesh_sizes, stack_no_diamond, stack_with_diamond, watcher_points
 from heatflow_amd.materials import Material
-from heatflow_amd.mesh import Mesh, load_mesh_arrays, read_msh
+from heatflow_amd.mesh import Mesh, load_mesh_arrays, read_msh, reorder_mesh
 
 
 def test_yaml_mantissas_without_a_dot_load_as_strings_and_are_coerced():
@@ -266,3 +266,20 @@ def test_mesher_on_random_layer_stacks(seed):
         legs = np.sort(np.stack([np.linalg.norm(p1 - p0, axis=1), np.linalg.norm(p2 - p1, axis=1),
                                  np.linalg.norm(p0 - p2, axis=1)], axis=1)[sel], axis=1)
         assert legs[:, 1].max() <= m.mesh_size * (1 + 1e-9)
+
+
+def test_reorder_mesh_is_a_consistent_renumbering():
+    cfg, st, mesh = build_case("geballe_with_diamond", 16.0)
+    rng = np.random.default_rng(0)
+    shuffle = rng.permutation(len(mesh.coords))                  # scramble like an external mesher would
+    inv = np.empty_like(shuffle)
+    inv[shuffle] = np.arange(len(shuffle))
+    c_s, t_s = mesh.coords[shuffle], inv[mesh.tris][rng.permutation(len(mesh.tris))]
+    tags_s = np.arange(len(t_s), dtype=np.int32)                 # unique tags: track every triangle
+    c2, t2, g2, perm = reorder_mesh(c_s, t_s, tags_s)
+    assert np.array_equal(c2, c_s[perm]) and sorted(g2.tolist()) == list(range(len(t_s)))
+    # every triangle keeps its three vertex positions
+    assert np.array_equal(np.sort(c2[t2].reshape(len(t2), -1), axis=1), np.sort(c_s[t_s][g2].reshape(len(t2), -1), axis=1))
+    # locality: mean |node index spread| inside a triangle shrinks by a large factor
+    spread = lambda t: np.mean(t.max(axis=1) - t.min(axis=1))
+    assert spread(t2) < 0.1 * spread(t_s)
