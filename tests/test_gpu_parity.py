@@ -568,3 +568,56 @@ def test_general_triangles_random_meshes(hip, seed):
             g_ref = proj.project(refs[2])
             scale = np.abs(g_ref).max()
             assert np.abs(gz - g_ref[:, 0]).max() <= 1e-8 * scale and np.abs(gr - g_ref[:, 1]).max() <= 1e-8 * scale
+
+
+def test_call_order_state_machine(hip, case_no_diamond_small):
+    """Out-of-order and repeated calls return error codes (never crash) and leave the context usable;
+    re-assembling with another dt / preconditioner / Dirichlet set between steps gives the oracle's numbers."""
+    from oracle import heat_oracle as ho
+
+    cfg, stack, mesh = case_no_diamond_small
+    tag_to_k, tag_to_rc = material_tables(stack, mesh)
+    tl = sorted(tag_to_k)
+    n = len(mesh.coords)
+    with hip.HeatflowHIP(0) as be:
+        for call in (lambda: be.set_materials(tl, [1.0] * 5, [1.0] * 5), lambda: be.set_dirichlet([0]),
+                     lambda: be.flux_setup(), lambda: be.get_csr(), lambda: be.time_kernel(hip.K_SPMV, 2)):
+            with pytest.raises((hip.HipError, ValueError)):
+                call()                                               # nothing works before set_mesh
+        be.set_mesh(mesh.coords, mesh.tris, mesh.tags)
+        with pytest.raises(hip.HipError):
+            be.flux_project()
+        with pytest.raises(hip.HipError):
+            be.update_kappa([1], [2.0])
+        be.set_materials(tl, [tag_to_k[t] for t in tl], [tag_to_rc[t] for t in tl])
+        with pytest.raises(ValueError):
+            be.assemble(-1.0)
+        with pytest.raises(ValueError):
+            be.assemble(1e-7, 9)
+        be.assemble(1e-7, 1)
+        with pytest.raises(ValueError):
+            be.step(np.zeros(3))                                     # wrong number of boundary values
+        be.set_dirichlet([5, 9, 2])                                  # invalidates the assembled operator
+        with pytest.raises(hip.HipError):
+            be.step(np.zeros(3))
+        with pytest.raises(ValueError):
+            be.set_precond(7)
+        # a valid sequence with changes between steps, checked against the oracle
+        u = np.full(n, 300.0)
+        dofs = np.array([5, 9, 2], dtype=np.int32)
+        plan = [(1e-7, 0), (1e-7, 1), (3e-8, 1), (3e-8, 0)]
+        be.set_state(u)
+        for dt, pc in plan:
+            be.set_precond(pc)
+            be.assemble(dt, 1)
+            g = np.array([350.0, 320.0, 400.0])
+            be.step(g, rtol=1e-12)
+            sol = ho.OracleSolver(mesh.coords, mesh.tris, mesh.tags, tag_to_k, tag_to_rc, dt,
+                                  [{"dofs": dofs[[0]], "value": 350.0}, {"dofs": dofs[[1]], "value": 320.0},
+                                   {"dofs": dofs[[2]], "value": 400.0}], u)
+            u = sol.step(dt)
+            assert np.abs(be.get_state() - u).max() <= 1e-6
+            be.set_state(u)
+        with pytest.raises(ValueError):
+            be.sample([n])                                           # node out of range
+        assert be.sample([5])[0] == 350.0
