@@ -171,9 +171,46 @@ inline double gershgorin_rho(const Csr& A, const std::vector<double>& d) {  // b
 struct Level {
   Csr A;                    // operator of this level (level 0: not stored here, the caller owns it)
   Csr P, R;                 // to / from the next coarser level (empty on the coarsest)
+  // Intermediate levels (neither finest nor coarsest) also carry the V(1,1) cycle's two legs as single
+  // operators, so that a level costs two SpMV launches instead of four (same cycle in exact arithmetic):
+  //   down:  b_{l+1} = R (b - A w D^-1 b)                       = Rt b,           Rt = ((I - w D^-1 A) P)^T
+  //   up:    x = (I - w D^-1 A)(w D^-1 b + P e) + w D^-1 b       = GP [b; e],      GP = [2wD^-1 - w^2 D^-1 A D^-1 | (I - w D^-1 A) P]
+  Csr Rt, GP;
   std::vector<double> dinv;
   double omega = 0.0;       // Jacobi damping 4 / (3 rho)
 };
+
+// S = I - w D^-1 A (same pattern as A; A carries its diagonal)
+inline Csr jacobi_iteration_matrix(const Csr& A, const std::vector<double>& dinv, double w) {
+  Csr S = A;
+  for (int i = 0; i < A.nrow; ++i)
+    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k)
+      S.val[k] = (A.idx[k] == i ? 1.0 : 0.0) - w * dinv[i] * A.val[k];
+  return S;
+}
+
+// [G | Pt] with G = 2 w D^-1 - w^2 D^-1 A D^-1 (pattern of A) and the columns of Pt shifted by A.ncol
+inline Csr fused_up_leg(const Csr& A, const std::vector<double>& dinv, double w, const Csr& Pt) {
+  Csr C;
+  C.nrow = A.nrow;
+  C.ncol = A.ncol + Pt.ncol;
+  C.ptr.assign(static_cast<size_t>(A.nrow) + 1, 0);
+  C.idx.reserve(A.idx.size() + Pt.idx.size());
+  C.val.reserve(A.idx.size() + Pt.idx.size());
+  for (int i = 0; i < A.nrow; ++i) {
+    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+      const int j = A.idx[k];
+      C.idx.push_back(j);
+      C.val.push_back((j == i ? 2.0 * w * dinv[i] : 0.0) - w * w * dinv[i] * A.val[k] * dinv[j]);
+    }
+    for (int k = Pt.ptr[i]; k < Pt.ptr[i + 1]; ++k) {
+      C.idx.push_back(A.ncol + Pt.idx[k]);
+      C.val.push_back(Pt.val[k]);
+    }
+    C.ptr[i + 1] = static_cast<int>(C.idx.size());
+  }
+  return C;
+}
 
 struct Hierarchy {
   std::vector<Level> levels;          // levels[0].A is left empty (the fine operator lives on the device)
@@ -220,6 +257,11 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
       L.R = transpose(L.P);
       Csr AP = spgemm(A, L.P);
       Csr Ac = spgemm(L.R, AP);
+      if (lev > 0) {                                 // intermediate level: fused legs of the cycle
+        const Csr Pt = spgemm(jacobi_iteration_matrix(A, L.dinv, L.omega), L.P);
+        L.Rt = transpose(Pt);
+        L.GP = fused_up_leg(A, L.dinv, L.omega, Pt);
+      }
       if (lev > 0) L.A = std::move(A);               // level 0's operator stays with the caller
       H.levels.push_back(std::move(L));
       A = std::move(Ac);

@@ -109,7 +109,15 @@ struct hf_ctx {
     int nrow = 0, ncol = 0, lanes = 8; int64_t nnz = 0; int32_t *ptr = nullptr, *idx = nullptr; double* val = nullptr;
     int rpc = 0, nchunks = 0, chunk_nnz = 0;   // LDS-staged (stream) kernel geometry; rpc = 0 -> use the sub-wave kernel
   };
-  struct DevLevel { DevCsr A, P, R; double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr; double omega = 0; int n = 0; };
+  // Levels 1..nl-2 run the cycle through the fused legs Rt / GP (amg_host.hpp): `cat` = [b_l ; result of level l+1]
+  // is GP's operand, `b` aliases its head; a level's result goes to `res` (the tail of the finer level's cat,
+  // or the level's own x on level 1).  The coarsest level owns a zero-padded b (the dense solve reads pairs).
+  struct DevLevel {
+    DevCsr A, P, R, Rt, GP;
+    double *dinv = nullptr, *x = nullptr, *cat = nullptr, *b = nullptr, *res = nullptr;
+    bool own_b = false;
+    double omega = 0; int n = 0;
+  };
   std::vector<DevLevel> amg;
   double* d_coarse_inv = nullptr;
   int coarse_n = 0, coarse_ld = 0;   // dense inverse, row-major with an even leading dimension (16-byte row loads)

@@ -397,6 +397,20 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
     const int r1 = min(n, r0 + rpc);
     const int k0 = rowptr[r0];
     const int k1 = rowptr[r1];
+    // row-wise epilogue operands are requested before the product stream so their latency hides under it
+    const int prow = r0 + threadIdx.x;
+    const bool pin = prow < r1;
+    int pa = 0, pb = 0;
+    double e_b = 0.0, e_d = 0.0, e_y = 0.0, e_p = 0.0, e_x = 0.0;
+    if (pin) {
+      pa = rowptr[prow] - k0;
+      pb = rowptr[prow + 1] - k0;
+      if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8) e_b = bvec[prow];
+      if (MODE == 2 || MODE == 4 || MODE == 5 || MODE == 7) e_d = dinv[prow];
+      if (MODE == 6 || (MODE == 9 && !first9)) e_y = y[prow];
+      if (MODE == 9 && !first9) e_p = pvec[prow];
+      if (MODE == 1 || MODE == 4 || MODE == 8 || MODE == 9) e_x = x[prow];
+    }
     if (MODE != 7) {  // products in nnz order; HF_UNROLL independent value/index loads and gathers in flight per lane
       int k = k0 + threadIdx.x;
       for (; k + (HF_UNROLL - 1) * TS < k1; k += HF_UNROLL * TS) {
@@ -418,51 +432,46 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
       }
     }
     __syncthreads();
-    const int row = r0 + threadIdx.x;
-    if (row < r1) {
-      const int a = rowptr[row] - k0, b = rowptr[row + 1] - k0;
+    if (pin) {
+      const int row = prow;
       double s = 0.0;
-      for (int j = a; j < b; ++j) s += sprod[j];
+      for (int j = pa; j < pb; ++j) s += sprod[j];
       if (MODE == 0) {
         y[row] = s;
       } else if (MODE == 1) {
         y[row] = s;
-        acc0 += x[row] * s;
+        acc0 += e_x * s;
       } else if (MODE == 2) {
-        const double bi = bvec[row], di = dinv[row];
-        const double ri = bi - s;
-        const double zi = di * ri;
+        const double ri = e_b - s;
+        const double zi = e_d * ri;
         y[row] = ri;
         pvec[row] = zi;
         acc0 += ri * zi;
         acc1 += zi * zi;
-        acc2 += (di * bi) * (di * bi);
+        acc2 += (e_d * e_b) * (e_d * e_b);
       } else if (MODE == 3) {
-        y[row] = bvec[row] - s;
+        y[row] = e_b - s;
       } else if (MODE == 4) {
-        const double bi = bvec[row];
-        const double yi = x[row] + w * dinv[row] * (bi - s);
+        const double yi = e_x + w * e_d * (e_b - s);
         y[row] = yi;
-        acc0 += bi * yi;
+        acc0 += e_b * yi;
       } else if (MODE == 5) {
-        const double bi = bvec[row], di = dinv[row];
-        const double ri = bi - s;
+        const double ri = e_b - s;
         y[row] = ri;
-        pvec[row] = w * di * ri;
-        acc1 += (di * ri) * (di * ri);
-        acc2 += (di * bi) * (di * bi);
+        pvec[row] = w * e_d * ri;
+        acc1 += (e_d * ri) * (e_d * ri);
+        acc2 += (e_d * e_b) * (e_d * e_b);
       } else if (MODE == 6) {
-        y[row] += s;
+        y[row] = e_y + s;
       } else if (MODE == 7) {
-        const double bi = bvec[row];
-        pvec[row] = w * dinv[row] * bi;
-        y[row] = bi - s;
+        pvec[row] = w * e_d * e_b;
+        y[row] = e_b - s;
       } else if (MODE == 8) {
         y[row] = s;
-        pvec[row] = 2.0 * x[row] - bvec[row];
+        pvec[row] = 2.0 * e_x - e_b;
       } else {
-        const double api = first9 ? s : s + beta * y[row];          // first iteration: p = z, Ap = A z
-        const double pi = first9 ? x[row] : x[row] + beta * pvec[row];
+        const double api = first9 ? s : s + beta * e_y;          // first iteration: p = z, Ap = A z
+        const double pi = first9 ? e_x : e_x + beta * e_p;
         y[row] = api;
         pvec[row] = pi;
         acc0 += pi * api;

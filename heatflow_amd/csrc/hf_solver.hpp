@@ -18,9 +18,9 @@ void free_amg(hf_ctx* ctx) {
   drop_graphs(ctx);
   for (size_t l = 0; l < ctx->amg.size(); ++l) {
     DevLevel& L = ctx->amg[l];
-    if (l > 0) { free_dev_csr(L.A); dev_free(&L.dinv); dev_free(&L.x); dev_free(&L.b); }
-    free_dev_csr(L.P); free_dev_csr(L.R);
-    dev_free(&L.x2); dev_free(&L.r);
+    if (l > 0) { free_dev_csr(L.A); dev_free(&L.dinv); dev_free(&L.x); dev_free(&L.cat); }
+    if (L.own_b) dev_free(&L.b);
+    free_dev_csr(L.P); free_dev_csr(L.R); free_dev_csr(L.Rt); free_dev_csr(L.GP);
   }
   ctx->amg.clear();
   dev_free(&ctx->d_coarse_inv);
@@ -84,11 +84,24 @@ int build_amg(hf_ctx* ctx) {
       HF_TRY(upload_csr(ctx, hl.A, L.A));
       HF_TRY(dev_alloc(ctx, &L.dinv, L.n));
       HF_HIP(copy_sync(ctx, L.dinv, hl.dinv.data(), sizeof(double) * L.n, hipMemcpyHostToDevice));
-      HF_TRY(dev_alloc(ctx, &L.x, L.n + 2));
-      HF_TRY(dev_alloc(ctx, &L.b, L.n + 2));
-      HF_TRY(dev_alloc(ctx, &L.x2, L.n + 2));
-      HF_TRY(dev_alloc(ctx, &L.r, L.n + 2));
-      HF_HIP(hipMemsetAsync(L.b, 0, sizeof(double) * (L.n + 2), ctx->stream));   // the dense solve reads b in pairs
+      if (l + 1 < nl) {                       // intermediate level: b is the head of GP's operand
+        const size_t len = static_cast<size_t>(L.n) + hl.P.ncol + 2;
+        HF_TRY(dev_alloc(ctx, &L.cat, len));
+        HF_HIP(hipMemsetAsync(L.cat, 0, sizeof(double) * len, ctx->stream));
+        L.b = L.cat;
+        HF_TRY(upload_csr(ctx, hl.Rt, L.Rt));
+        HF_TRY(upload_csr(ctx, hl.GP, L.GP));
+      } else {                                // coarsest: the dense solve reads b in pairs -> zero pad
+        HF_TRY(dev_alloc(ctx, &L.b, L.n + 2));
+        L.own_b = true;
+        HF_HIP(hipMemsetAsync(L.b, 0, sizeof(double) * (L.n + 2), ctx->stream));
+      }
+      if (l == 1) {
+        HF_TRY(dev_alloc(ctx, &L.x, L.n + 2));
+        L.res = L.x;
+      } else {
+        L.res = ctx->amg[l - 1].cat + ctx->amg[l - 1].n;
+      }
     }
     if (l + 1 < nl) { HF_TRY(upload_csr(ctx, hl.P, L.P)); HF_TRY(upload_csr(ctx, hl.R, L.R)); }
   }
@@ -163,9 +176,9 @@ void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y, const do
 
 // z = B r: one V(1,1) cycle.  Fixed buffer roles (no pointer swaps, so captured graphs and eager
 // launches always agree): on entry d_z holds w0 D^-1 r (written by the update / start kernel); on exit
-// d_z2 holds z and part_rz[out_slot] the partials of r.z.  On every coarser level x carries the
-// pre-smoothed iterate plus the coarse correction and x2 the post-smoothed result (the coarsest
-// level's result is its x).
+// d_z2 holds z and part_rz[out_slot] the partials of r.z.  The finest level runs its two sweeps explicitly
+// (its operator changes with every re-assembly); every intermediate level is two launches, the fused
+// down leg Rt and the fused up leg GP (amg_host.hpp), the coarsest level a dense mat-vec.
 void vcycle(hf_ctx* c, int out_slot) {
   const int nl = static_cast<int>(c->amg.size());
   DevLevel& L0 = c->amg[0];
@@ -174,30 +187,21 @@ void vcycle(hf_ctx* c, int out_slot) {
     return;
   }
   launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r);                 // t = r - A z
-  launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);                                // b1 = R0 t
-  for (int l = 1; l + 1 < nl; ++l) {
-    DevLevel& L = c->amg[l];
-    launch_vec<4>(c, L.A, L.b, L.r, L.b, L.dinv, L.omega, L.x);                 // x_l = w D^-1 b_l ; r_l = b_l - A_l x_l
-    launch_vec<0>(c, L.R, L.r, c->amg[l + 1].b);                                // b_{l+1} = R_l r_l
-  }
+  launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);                                // b_1 = R_0 t
+  for (int l = 1; l + 1 < nl; ++l) launch_vec<0>(c, c->amg[l].Rt, c->amg[l].b, c->amg[l + 1].b);   // b_{l+1} = Rt_l b_l
   {
     DevLevel& Lc = c->amg[nl - 1];
     if (c->coarse_n > 0) {
       const int g = std::max(1, std::min((Lc.n + 1) / 2, 2048));
-      hipLaunchKernelGGL(k_dense_mv, dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv, Lc.b, Lc.x,
+      hipLaunchKernelGGL(k_dense_mv, dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv, Lc.b, Lc.res,
                          c->d_scal);
     } else {
       const int g = std::max(1, std::min((Lc.n + TPB - 1) / TPB, 1024));
-      hipLaunchKernelGGL(k_scale, dim3(g), dim3(TPB), 0, c->stream, Lc.n, Lc.omega, Lc.dinv, Lc.b, Lc.x, c->d_scal);
+      hipLaunchKernelGGL(k_scale, dim3(g), dim3(TPB), 0, c->stream, Lc.n, Lc.omega, Lc.dinv, Lc.b, Lc.res, c->d_scal);
     }
   }
-  for (int l = nl - 2; l >= 1; --l) {
-    DevLevel& L = c->amg[l];
-    const double* coarse = (l + 1 == nl - 1) ? c->amg[l + 1].x : c->amg[l + 1].x2;
-    launch_vec<1>(c, L.P, coarse, L.x);                                         // x_l += P_l x_{l+1}
-    launch_vec<3>(c, L.A, L.x, L.x2, L.b, L.dinv, L.omega);                     // post-smooth -> x2
-  }
-  launch_vec<1>(c, L0.P, (nl == 2) ? c->amg[1].x : c->amg[1].x2, c->d_z);       // z += P0 x_1
+  for (int l = nl - 2; l >= 1; --l) launch_vec<0>(c, c->amg[l].GP, c->amg[l].cat, c->amg[l].res);  // x_l = GP_l [b_l; x_{l+1}]
+  launch_vec<1>(c, L0.P, c->amg[1].res, c->d_z);                                // z += P_0 x_1
   launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
 }
 
