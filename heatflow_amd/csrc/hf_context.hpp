@@ -107,6 +107,7 @@ struct hf_ctx {
   bool amg_ready = false;
   struct DevCsr {
     int nrow = 0, ncol = 0, lanes = 8; int64_t nnz = 0; int32_t *ptr = nullptr, *idx = nullptr; double* val = nullptr;
+    int max_row = 0;
     int rpc = 0, nchunks = 0, chunk_nnz = 0;   // LDS-staged (stream) kernel geometry; rpc = 0 -> use the sub-wave kernel
   };
   // Levels 1..nl-2 run the cycle through the fused legs Rt / GP (amg_host.hpp): `cat` = [b_l ; result of level l+1]

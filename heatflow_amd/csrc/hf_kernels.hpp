@@ -336,14 +336,11 @@ __global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* 
 // park val*x[col] in LDS; then lane t sums the products of row t in column order.  The
 // summation order per row is the CSR order -> bitwise reproducible, no atomics.
 //   MODE 0: y = A x
-//   MODE 1: y = A x and partial sums of x.y             (PCG: Ap, p.Ap)
 //   MODE 2: r = b - A x; p = D^-1 r; partials r.p, p.p, (D^-1 b)^2   (PCG start)
 //   MODE 3: y = b - A x                                              (multigrid residual)
 //   MODE 4: y = x + w D^-1 (b - A x), partials b.y                   (damped-Jacobi sweep, fused r.z)
 //   MODE 5: y = b - A x; p = w D^-1 y; partials (D^-1 y)^2, (D^-1 b)^2   (AMG-PCG start)
 //   MODE 6: y += A x                                                 (multigrid prolongation)
-//   MODE 7: p = w D^-1 b; y = b - A p   (first Jacobi sweep from zero fused with the residual;
-//           the products gather w*dinv[col]*b[col], so p is never read back)
 //   MODE 8: y = A x; p = 2 x - b        (RHS b = M u^n fused with the extrapolated start
 //           2 u^n - u^{n-1} of the next solve; `b` carries u^{n-1})
 //   MODE 9: PCG iteration head (x = z): convergence test, beta, Ap <- A z + beta Ap, p <- z + beta p,
@@ -363,7 +360,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
                                               int parity) {
   extern __shared__ double sprod[];
   __shared__ double s4[TS / 64];
-  if ((MODE == 1 || MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 9) && scal->done) return;
+  if ((MODE == 3 || MODE == 4 || MODE == 6 || MODE == 9) && scal->done) return;
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   double beta = 0.0;
   bool first9 = false;
@@ -405,31 +402,27 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
     if (pin) {
       pa = rowptr[prow] - k0;
       pb = rowptr[prow + 1] - k0;
-      if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8) e_b = bvec[prow];
-      if (MODE == 2 || MODE == 4 || MODE == 5 || MODE == 7) e_d = dinv[prow];
+      if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 8) e_b = bvec[prow];
+      if (MODE == 2 || MODE == 4 || MODE == 5) e_d = dinv[prow];
       if (MODE == 6 || (MODE == 9 && !first9)) e_y = y[prow];
       if (MODE == 9 && !first9) e_p = pvec[prow];
-      if (MODE == 1 || MODE == 4 || MODE == 8 || MODE == 9) e_x = x[prow];
+      if (MODE == 4 || MODE == 8 || MODE == 9) e_x = x[prow];
     }
-    if (MODE != 7) {  // products in nnz order; HF_UNROLL independent value/index loads and gathers in flight per lane
-      int k = k0 + threadIdx.x;
-      for (; k + (HF_UNROLL - 1) * TS < k1; k += HF_UNROLL * TS) {
-        int c[HF_UNROLL];
-        double v[HF_UNROLL], xv[HF_UNROLL];
+    // products in nnz order: HF_UNROLL predicated value/index loads, then the gathers, in flight per lane
+    for (int k = k0 + threadIdx.x; k < k1; k += HF_UNROLL * TS) {
+      int c[HF_UNROLL];
+      double v[HF_UNROLL], xv[HF_UNROLL];
 #pragma unroll
-        for (int u = 0; u < HF_UNROLL; ++u) { c[u] = colidx[k + u * TS]; v[u] = vals[k + u * TS]; }
-#pragma unroll
-        for (int u = 0; u < HF_UNROLL; ++u) xv[u] = x[c[u]];
-#pragma unroll
-        for (int u = 0; u < HF_UNROLL; ++u) sprod[k - k0 + u * TS] = v[u] * xv[u];
+      for (int u = 0; u < HF_UNROLL; ++u) {
+        const bool in = k + u * TS < k1;
+        c[u] = in ? colidx[k + u * TS] : 0;
+        v[u] = in ? vals[k + u * TS] : 0.0;
       }
-      for (; k < k1; k += TS) sprod[k - k0] = vals[k] * x[colidx[k]];
-    }
-    if (MODE == 7) {  // operand is w D^-1 b, formed on the fly
-      for (int k = k0 + threadIdx.x; k < k1; k += TS) {
-        const int c = colidx[k];
-        sprod[k - k0] = vals[k] * (w * dinv[c] * bvec[c]);
-      }
+#pragma unroll
+      for (int u = 0; u < HF_UNROLL; ++u) xv[u] = (k + u * TS < k1) ? x[c[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < HF_UNROLL; ++u)
+        if (k + u * TS < k1) sprod[k - k0 + u * TS] = v[u] * xv[u];
     }
     __syncthreads();
     if (pin) {
@@ -438,9 +431,6 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
       for (int j = pa; j < pb; ++j) s += sprod[j];
       if (MODE == 0) {
         y[row] = s;
-      } else if (MODE == 1) {
-        y[row] = s;
-        acc0 += e_x * s;
       } else if (MODE == 2) {
         const double ri = e_b - s;
         const double zi = e_d * ri;
@@ -463,9 +453,6 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
         acc2 += (e_d * e_b) * (e_d * e_b);
       } else if (MODE == 6) {
         y[row] = e_y + s;
-      } else if (MODE == 7) {
-        pvec[row] = w * e_d * e_b;
-        y[row] = e_b - s;
       } else if (MODE == 8) {
         y[row] = s;
         pvec[row] = 2.0 * e_x - e_b;
@@ -480,7 +467,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
     __syncthreads();
   }
   // consumers sum `npart` slots in a fixed order; this launch has fewer workgroups, the rest are zeros
-  if (MODE == 1 || MODE == 2 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {
+  if (MODE == 2 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {
     const double t0 = block_sum<TS / 64>(acc0, s4);
     if (threadIdx.x == 0) {
       part0[blockIdx.x] = t0;
@@ -556,36 +543,71 @@ __global__ __launch_bounds__(TPB) void k_pcg_update(int n, int nchunks, int P, i
 
 // ------------------------------------------------------------------------------------------
 // Generic CSR SpMV for the multigrid transfer operators and coarse levels: LANES lanes of a
-// wavefront share one row (4..64 by the average row length), fixed-order shuffle reduction.
-//   VMODE 0: y = A x      1: y += A x      2: y = b - A x      3: y = x + w D^-1 (b - A x)
-//   VMODE 4: xs = w D^-1 b (stored to xout), y = b - A xs
+// wavefront share one row (4..64 by the average row length), four predicated loads + gathers in
+// flight per lane (the fused legs have rows of hundreds of entries), fixed-order shuffle reduction.
+//   VMODE 0: y = A x      1: y += A x
 // ------------------------------------------------------------------------------------------
 template <int LANES, int VMODE>
 __global__ __launch_bounds__(TPB) void k_spmv_vec(int nrow, const int32_t* __restrict__ ptr,
                                                   const int32_t* __restrict__ idx, const double* __restrict__ val,
                                                   const double* __restrict__ x, double* __restrict__ y,
-                                                  const double* __restrict__ b, const double* __restrict__ dinv,
-                                                  double w, const Scal* __restrict__ scal, double* __restrict__ xout) {
+                                                  const Scal* __restrict__ scal) {
   if (scal->done) return;
   const int lane = threadIdx.x % LANES;
   const int rows_per_pass = (gridDim.x * TPB) / LANES;
   for (int row = (blockIdx.x * TPB + threadIdx.x) / LANES; row < nrow; row += rows_per_pass) {
-    double s = 0.0;
     const int k1 = ptr[row + 1];
-    if (VMODE == 4) {
-      for (int k = ptr[row] + lane; k < k1; k += LANES) { const int c = idx[k]; s += val[k] * (w * dinv[c] * b[c]); }
-    } else {
-      for (int k = ptr[row] + lane; k < k1; k += LANES) s += val[k] * x[idx[k]];
+    const double y0 = (VMODE == 1 && lane == 0) ? y[row] : 0.0;
+    double s = 0.0;
+    for (int k = ptr[row] + lane; k < k1; k += 4 * LANES) {
+      int c[4];
+      double v[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = k + u * LANES < k1;
+        c[u] = in ? idx[k + u * LANES] : 0;
+        v[u] = in ? val[k + u * LANES] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = (k + u * LANES < k1) ? x[c[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u] * xv[u];
     }
 #pragma unroll
     for (int o = LANES / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LANES);
-    if (lane == 0) {
-      if (VMODE == 0) y[row] = s;
-      else if (VMODE == 1) y[row] += s;
-      else if (VMODE == 2) y[row] = b[row] - s;
-      else if (VMODE == 3) y[row] = x[row] + w * dinv[row] * (b[row] - s);
-      else { const double bi = b[row]; xout[row] = w * dinv[row] * bi; y[row] = bi - s; }
+    if (lane == 0) y[row] = (VMODE == 1) ? y0 + s : s;
+  }
+}
+
+// Same operation for operators with very long rows (the fused down leg onto a small level): a whole
+// workgroup per row, four predicated loads + gathers in flight per lane, fixed-order block reduction.
+template <int VMODE>
+__global__ __launch_bounds__(TPB) void k_spmv_row(int nrow, const int32_t* __restrict__ ptr,
+                                                  const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                  const double* __restrict__ x, double* __restrict__ y,
+                                                  const Scal* __restrict__ scal) {
+  __shared__ double s4[TPB / 64];
+  if (scal->done) return;
+  for (int row = blockIdx.x; row < nrow; row += gridDim.x) {
+    const int k1 = ptr[row + 1];
+    const double y0 = (VMODE == 1 && threadIdx.x == 0) ? y[row] : 0.0;
+    double s = 0.0;
+    for (int k = ptr[row] + threadIdx.x; k < k1; k += 4 * TPB) {
+      int c[4];
+      double v[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = k + u * TPB < k1;
+        c[u] = in ? idx[k + u * TPB] : 0;
+        v[u] = in ? val[k + u * TPB] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = (k + u * TPB < k1) ? x[c[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u] * xv[u];
     }
+    const double t = block_sum<TPB / 64>(s, s4);
+    if (threadIdx.x == 0) y[row] = (VMODE == 1) ? y0 + t : t;
   }
 }
 

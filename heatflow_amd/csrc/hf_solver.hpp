@@ -30,17 +30,20 @@ void free_amg(hf_ctx* ctx) {
 
 int lanes_for(const amg::Csr& m) {
   const double avg = m.nrow ? static_cast<double>(m.nnz()) / m.nrow : 1.0;
-  return avg <= 4.5 ? 4 : avg <= 9.0 ? 8 : avg <= 18.0 ? 16 : avg <= 36.0 ? 32 : 64;
+  return avg <= 4.5 ? 4 : avg <= 9.0 ? 8 : avg <= 18.0 ? 16 : avg <= 36.0 ? 32 : avg <= 128.0 ? 64 : 256;
 }
 
 int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d) {
   d.nrow = h.nrow; d.ncol = h.ncol; d.nnz = h.nnz(); d.lanes = lanes_for(h);
+  for (int i = 0; i < h.nrow; ++i) d.max_row = std::max(d.max_row, h.ptr[i + 1] - h.ptr[i]);
   d.rpc = 0;
-  if (h.nrow >= 100000) {  // enough 512-row chunks to fill the chip: LDS-staged kernel, chunk products within 64 KB
+  static const int min_rows = std::getenv("HEATFLOW_STREAM_MIN_ROWS") ? std::atoi(std::getenv("HEATFLOW_STREAM_MIN_ROWS")) : 100000;
+  static const int max_nnz = std::getenv("HEATFLOW_STREAM_NNZ") ? std::atoi(std::getenv("HEATFLOW_STREAM_NNZ")) : 4096;
+  if (h.nrow >= min_rows) {  // enough 512-row chunks to fill the chip: LDS-staged kernel, chunk products within 64 KB
     for (int rpc = TS; rpc >= 32; rpc /= 2) {
       int mx = 0;
       for (int r0 = 0; r0 < h.nrow; r0 += rpc) mx = std::max(mx, h.ptr[std::min(h.nrow, r0 + rpc)] - h.ptr[r0]);
-      if (mx <= 8000) { d.rpc = rpc; d.nchunks = (h.nrow + rpc - 1) / rpc; d.chunk_nnz = mx; break; }
+      if (mx <= max_nnz) { d.rpc = rpc; d.nchunks = (h.nrow + rpc - 1) / rpc; d.chunk_nnz = mx; break; }
     }
   }
   HF_TRY(dev_alloc(ctx, &d.ptr, h.ptr.size()));
@@ -105,6 +108,16 @@ int build_amg(hf_ctx* ctx) {
     }
     if (l + 1 < nl) { HF_TRY(upload_csr(ctx, hl.P, L.P)); HF_TRY(upload_csr(ctx, hl.R, L.R)); }
   }
+  if (std::getenv("HEATFLOW_DEBUG")) {
+    auto show = [](const char* nm, size_t l, const DevCsr& m) {
+      if (m.nrow) std::fprintf(stderr, "[amg] level %zu %-2s %8d x %8d nnz %9lld (%.1f/row, max %d) %s rpc %d lanes %d\n", l, nm, m.nrow, m.ncol,
+                               static_cast<long long>(m.nnz), static_cast<double>(m.nnz) / m.nrow, m.max_row, m.rpc ? "stream" : "vec", m.rpc, m.lanes);
+    };
+    for (size_t l = 0; l < nl; ++l) {
+      show("A", l, ctx->amg[l].A); show("P", l, ctx->amg[l].P); show("R", l, ctx->amg[l].R);
+      show("Rt", l, ctx->amg[l].Rt); show("GP", l, ctx->amg[l].GP);
+    }
+  }
   // coarsest level: dense inverse by Gauss-Jordan on the device
   ctx->coarse_n = 0;
   if (nl > 1 && H.coarse_n > 0 && H.coarse_n <= 4096) {
@@ -146,24 +159,29 @@ int build_amg(hf_ctx* ctx) {
   return HF_OK;
 }
 
-// VMODE 0: y = A x, 1: y += A x, 2: y = b - A x, 3: y = x + w D^-1 (b - A x); LDS-staged kernel when the
-// matrix is big enough to fill the chip, sub-wave kernel otherwise.
+// VMODE 0: y = A x, 1: y += A x; LDS-staged kernel when the matrix is big enough to fill the chip,
+// sub-wave kernel otherwise.
 template <int VMODE>
-void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y, const double* b = nullptr,
-                const double* dinv = nullptr, double w = 0.0, double* xout = nullptr) {
+void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
   if (m.rpc > 0) {
-    constexpr int SM = VMODE == 0 ? 0 : VMODE == 1 ? 6 : VMODE == 2 ? 3 : VMODE == 3 ? 4 : 7;
+    constexpr int SM = VMODE == 0 ? 0 : 6;
     int grid = std::min(m.nchunks, MAXP);
     if (grid >= 64) grid &= ~7;
     hipLaunchKernelGGL(k_spmv<SM>, dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream, m.nrow,
-                       m.nchunks, m.rpc, m.ptr, m.idx, m.val, x, y, c->d_scal, static_cast<double*>(nullptr), b, dinv,
-                       xout, static_cast<double*>(nullptr), static_cast<double*>(nullptr), w, 0, 0);
+                       m.nchunks, m.rpc, m.ptr, m.idx, m.val, x, y, c->d_scal, static_cast<double*>(nullptr),
+                       static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), static_cast<double*>(nullptr),
+                       static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0.0, 0, 0);
+    return;
+  }
+  if (m.lanes > 64) {  // very long rows: a workgroup per row
+    hipLaunchKernelGGL(k_spmv_row<VMODE>, dim3(std::max(1, std::min(m.nrow, 4096))), dim3(TPB), 0, c->stream, m.nrow, m.ptr,
+                       m.idx, m.val, x, y, c->d_scal);
     return;
   }
   const int lanes = m.lanes;
   const long long threads = static_cast<long long>(m.nrow) * lanes;
   const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 2048)));
-#define HF_VEC(L) hipLaunchKernelGGL((k_spmv_vec<L, VMODE>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, m.val, x, y, b, dinv, w, c->d_scal, xout)
+#define HF_VEC(L) hipLaunchKernelGGL((k_spmv_vec<L, VMODE>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, m.val, x, y, c->d_scal)
   switch (lanes) {
     case 4: HF_VEC(4); break;
     case 8: HF_VEC(8); break;
