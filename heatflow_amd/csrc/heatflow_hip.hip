@@ -63,7 +63,7 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_uprev); dev_free(&ctx->d_ustart);
   dev_free(&ctx->d_u); dev_free(&ctx->d_b); dev_free(&ctx->d_r); dev_free(&ctx->d_p); dev_free(&ctx->d_Ap);
-  free_amg(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
+  free_amg(ctx); free_responses(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
   dev_free(&ctx->d_M1); dev_free(&ctx->d_dinv1); dev_free(&ctx->d_gz); dev_free(&ctx->d_gr); dev_free(&ctx->d_bz); dev_free(&ctx->d_br);
   dev_free(&ctx->d_tmp); dev_free(&ctx->d_part_pAp); dev_free(&ctx->d_part_rz); dev_free(&ctx->d_part_zz);
   dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp);
@@ -132,6 +132,7 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_TRY(dev_alloc(ctx, &ctx->d_uprev, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_ustart, n));
   ctx->have_prev = false;
+  free_responses(ctx);
   HF_TRY(dev_alloc(ctx, &ctx->d_b, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_r, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_p, n));
@@ -214,6 +215,7 @@ int hf_set_dirichlet(hf_ctx* ctx, int32_t n_bc, const int32_t* dofs) {
   if (n_bc > 0) HF_HIP(copy_sync(ctx, ctx->d_bc_dofs, dofs, sizeof(int32_t) * n_bc, hipMemcpyHostToDevice));
   HF_TRY(build_lift(ctx));
   free_amg(ctx);
+  free_responses(ctx);
   ctx->assembled = false;  // A_hat depends on the BC set
   return HF_OK;
 }
@@ -251,6 +253,7 @@ int hf_assemble(hf_ctx* ctx, double dt, int32_t mode) {
   ctx->assembled = true;
   ctx->pred_iters = 0;
   ctx->have_prev = false;
+  free_responses(ctx);   // R depends on the operator
   return HF_OK;
 }
 
@@ -261,6 +264,21 @@ int hf_set_precond(hf_ctx* ctx, int32_t kind, int32_t reuse) {
   if (kind == 0) { (void)hipSetDevice(ctx->dev); free_amg(ctx); }
   ctx->precond = kind;
   ctx->amg_reuse = reuse ? 1 : 0;
+  return HF_OK;
+}
+
+int hf_set_start_vector(hf_ctx* ctx, int32_t kind) {
+  if (!ctx) return HF_ERR_ARG;
+  if (kind < 0 || kind > 2) return fail(ctx, HF_ERR_ARG, "hf_set_start_vector: unknown kind %d", kind);
+  ctx->start_kind = kind;
+  ctx->extrapolate = kind >= 1 ? 1 : 0;
+  if (kind == 0) ctx->have_prev = false;
+  return HF_OK;
+}
+
+int hf_get_response_solves(hf_ctx* ctx, int64_t* count) {
+  if (!ctx || !count) return HF_ERR_ARG;
+  *count = ctx->resp_solves;
   return HF_OK;
 }
 
@@ -346,6 +364,7 @@ int hf_set_state(hf_ctx* ctx, const double* u) {
   HF_HIP(hipMemcpyAsync(ctx->d_u, u, sizeof(double) * ctx->n, hipMemcpyHostToDevice, ctx->stream));
   HF_HIP(hipStreamSynchronize(ctx->stream));
   ctx->have_prev = false;
+  ctx->g_hist = 0;       // the state no longer continues the recursion the boundary history belongs to
   return HF_OK;
 }
 
@@ -379,8 +398,7 @@ int hf_step(hf_ctx* ctx, const double* g_bc, double rtol, double atol, int32_t m
   if (max_it <= 0 || rtol < 0 || atol < 0) return fail(ctx, HF_ERR_ARG, "hf_step: bad tolerances");
   HF_HIP(hipSetDevice(ctx->dev));
   HF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-  if (ctx->nbc > 0) HF_HIP(hipMemcpyAsync(ctx->d_g, g_bc, sizeof(double) * ctx->nbc, hipMemcpyHostToDevice, ctx->stream));
-  const int rc = step_device(ctx, rtol, atol, max_it);
+  const int rc = step_device(ctx, g_bc, rtol, atol, max_it);
   if (rc == HF_ERR_HIP) return rc;
   HF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
   HF_HIP(hipStreamSynchronize(ctx->stream));
@@ -401,12 +419,8 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, doubl
   for (int32_t q = 0; q < ns; ++q)
     if (nodes[q] < 0 || nodes[q] >= ctx->n) return fail(ctx, HF_ERR_ARG, "hf_run: node %d outside [0,%d)", nodes[q], ctx->n);
   HF_HIP(hipSetDevice(ctx->dev));
-  DevTemp<double> t_gall, t_sall;
-  double *&d_gall = t_gall.p, *&d_sall = t_sall.p;
-  if (ctx->nbc > 0) {
-    HF_TRY(dev_alloc(ctx, &d_gall, static_cast<size_t>(n_steps) * ctx->nbc));
-    HF_HIP(copy_sync(ctx, d_gall, g_all, sizeof(double) * n_steps * ctx->nbc, hipMemcpyHostToDevice));
-  }
+  DevTemp<double> t_sall;
+  double*& d_sall = t_sall.p;
   if (ns > 0) {
     HF_TRY(ensure_samples(ctx, ns));
     HF_TRY(dev_alloc(ctx, &d_sall, static_cast<size_t>(n_steps) * ns));
@@ -415,10 +429,7 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, doubl
   int rc = HF_OK;
   HF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
   for (int32_t s = 0; s < n_steps && rc == HF_OK; ++s) {
-    if (ctx->nbc > 0)
-      HF_HIP(hipMemcpyAsync(ctx->d_g, d_gall + static_cast<size_t>(s) * ctx->nbc, sizeof(double) * ctx->nbc,
-                            hipMemcpyDeviceToDevice, ctx->stream));
-    rc = step_device(ctx, rtol, atol, max_it);
+    rc = step_device(ctx, ctx->nbc > 0 ? g_all + static_cast<size_t>(s) * ctx->nbc : nullptr, rtol, atol, max_it);
     if (iters) iters[s] = ctx->h_scal->iters;
     if (ns > 0 && rc == HF_OK)
       hipLaunchKernelGGL(k_gather, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, ctx->d_u,

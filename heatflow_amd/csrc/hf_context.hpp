@@ -33,6 +33,7 @@ constexpr int NCOL = 32;       // max colours per row block (uint32 mask)
 #define HF_UNROLL 4
 #endif
 constexpr int MAXP = 1024;     // max workgroups per launch = partial-sum slots per array
+constexpr int MAXRESP = 4;     // boundary-response directions kept per operator
 constexpr int TS = 512;        // SpMV workgroup: 512 threads = 8 wavefronts own 512 consecutive rows per chunk
                                // (4 such workgroups per CU = 32 waves/CU; measured 20 % faster than 256x16)
 
@@ -92,6 +93,15 @@ struct hf_ctx {
   double *d_uprev = nullptr, *d_ustart = nullptr;   // u^{n-1} and the buffer of the next start vector (rotated with d_u)
   bool have_prev = false;
   int extrapolate = 1;         // start PCG from 2 u^n - u^{n-1} (same answer, fewer iterations)
+  // hf_set_start_vector kind 2: boundary-response correction of the start vector.  Host copies of the last two
+  // boundary vectors, an orthonormal set of directions seen in their second difference and, per direction d,
+  // the device vector w = R d (A_hat w = -lift(d), w_B = d).
+  int start_kind = 2;
+  std::vector<double> h_g0, h_g1;   // g^n, g^{n-1}
+  int g_hist = 0;
+  struct BcResponse { std::vector<double> dir; double* w = nullptr; };
+  std::vector<BcResponse> resp;
+  long long resp_solves = 0;
   double *d_tmp = nullptr;
   // device: reductions
   double *d_part_pAp = nullptr, *d_part_rz = nullptr, *d_part_zz = nullptr, *d_part_bn = nullptr;

@@ -611,6 +611,17 @@ __global__ __launch_bounds__(TPB) void k_spmv_row(int nrow, const int32_t* __res
   }
 }
 
+// start vector: u = base + sum_k c_k w_k   (base = 2 u^n - u^{n-1}; w_k = boundary responses)
+struct RespArgs { const double* w[MAXRESP]; double c[MAXRESP]; int k; };
+__global__ __launch_bounds__(TPB) void k_start_vector(int n, const double* __restrict__ base, RespArgs a,
+                                                      double* __restrict__ u) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+    double s = base[i];
+    for (int k = 0; k < a.k; ++k) s += a.c[k] * a.w[k][i];
+    u[i] = s;
+  }
+}
+
 // x = w D^-1 b  (first damped-Jacobi sweep from a zero guess)
 __global__ __launch_bounds__(TPB) void k_scale(int n, double w, const double* __restrict__ dinv,
                                                const double* __restrict__ b, double* __restrict__ x,

@@ -224,14 +224,14 @@ void vcycle(hf_ctx* c, int out_slot) {
 }
 
 // One multigrid-PCG iteration: iteration head (as above), update (alpha, x, r, z0 = w D^-1 r), V-cycle (z, r.z)
-void launch_amg_iteration(hf_ctx* c, int parity) {
+void launch_amg_iteration(hf_ctx* c, double* x, int parity) {
   const bool timed = c->prof && c->prof_used < PROF_PAIRS;
   hipEvent_t e0 = timed ? c->prof_ev[2 * c->prof_used] : nullptr, e1 = timed ? c->prof_ev[2 * c->prof_used + 1] : nullptr;
   launch_spmv<9>(c, c->d_A, c->d_z2, c->d_Ap, c->d_part_pAp, nullptr, c->d_p, c->d_part_rz, c->d_part_zz, 0.0, nullptr, e0,
                  e1, parity);
   if (timed) c->prof_used++;
   hipLaunchKernelGGL(k_pcg_update_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
-                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, c->d_u, c->d_r, c->d_p, c->d_Ap, c->d_dinv,
+                     c->d_part_pAp, c->d_part_rz, c->d_part_zz, x, c->d_r, c->d_p, c->d_Ap, c->d_dinv,
                      c->amg[0].omega, c->d_z);
   vcycle(c, parity ^ 1);
 }
@@ -274,7 +274,7 @@ hipGraphExec_t iteration_graph(hf_ctx* ctx, const LinSys& sys, bool use_amg, int
     return nullptr;
   }
   for (int k = 0; k < iters; ++k) {
-    if (use_amg) launch_amg_iteration(ctx, k & 1);
+    if (use_amg) launch_amg_iteration(ctx, sys.x, k & 1);
     else launch_pcg_iteration(ctx, sys, k & 1);
   }
   if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || graph == nullptr) {
@@ -329,7 +329,7 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
       for (int k = 0; k < burst; k += unit) HF_HIP(hipGraphLaunch(gexec, ctx->stream));
     } else {
       for (int k = 0; k < burst; ++k) {
-        if (use_amg) launch_amg_iteration(ctx, (launched + k) & 1);
+        if (use_amg) launch_amg_iteration(ctx, sys.x, (launched + k) & 1);
         else launch_pcg_iteration(ctx, sys, (launched + k) & 1);
       }
     }
@@ -349,16 +349,97 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
   return HF_OK;
 }
 
-// One time step with g already in d_g.  Leaves iteration count / residual in h_scal.
-int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
+void free_responses(hf_ctx* ctx) {
+  for (auto& r : ctx->resp) dev_free(&r.w);
+  ctx->resp.clear();
+  ctx->g_hist = 0;
+}
+
+// w = R d for a new boundary direction d:  A_hat w = -lift(d) on the free rows, w_B = d  (one extra solve).
+int solve_response(hf_ctx* ctx, const std::vector<double>& dir, int max_it, double** w_out) {
+  double* w = nullptr;
+  HF_TRY(dev_alloc(ctx, &w, ctx->n));
   const int nb = ctx->nbc;
+  HF_HIP(hipMemsetAsync(w, 0, sizeof(double) * ctx->n, ctx->stream));
+  HF_HIP(hipMemsetAsync(ctx->d_b, 0, sizeof(double) * ctx->n, ctx->stream));
+  HF_HIP(hipMemcpyAsync(ctx->d_g, dir.data(), sizeof(double) * nb, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->nlift_rows > 0)
+    hipLaunchKernelGGL(k_lift, dim3((ctx->nlift_rows + 255) / 256), dim3(256), 0, ctx->stream, ctx->nlift_rows,
+                       ctx->d_lift_rows, ctx->d_lift_ptr, ctx->d_lift_bc, ctx->d_lift_val, ctx->d_g, ctx->d_b);
+  hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, ctx->d_g, ctx->d_b, w);
+  const LinSys sys{ctx->d_A, ctx->d_dinv, w, ctx->d_b};
+  const bool use_amg = ctx->precond == 1 && ctx->amg_ready;
+  int pred = ctx->pred_iters;
+  int rc = pcg_solve(ctx, sys, use_amg, 1e-8, 0.0, max_it, &pred);
+  if (rc == HF_ERR_NOCONV && use_amg && ctx->h_scal->done == 2) rc = pcg_solve(ctx, sys, false, 1e-8, 0.0, max_it, &pred);
+  if (rc != HF_OK) { dev_free(&w); return rc; }
+  ctx->resp_solves += 1;
+  *w_out = w;
+  return HF_OK;
+}
+
+// Coefficients of the boundary-response correction for the step to g_new (host vector): the second difference
+// of the boundary values is expanded in the known directions; a remainder that is not rounding noise becomes a
+// new direction (one extra solve, at most MAXRESP per operator).  Never fatal: on failure the correction is off.
+int prepare_response(hf_ctx* ctx, const double* g_new, int max_it, RespArgs* ra) {
+  const int nb = ctx->nbc;
+  ra->k = 0;
+  std::vector<double> rem(nb);
+  double nrm2 = 0.0, gn2 = 0.0;
+  for (int q = 0; q < nb; ++q) {
+    rem[q] = (g_new[q] - ctx->h_g0[q]) - (ctx->h_g0[q] - ctx->h_g1[q]);
+    nrm2 += rem[q] * rem[q];
+    gn2 += g_new[q] * g_new[q];
+  }
+  if (!(nrm2 > 0.0)) return HF_OK;
+  for (size_t k = 0; k < ctx->resp.size(); ++k) {       // modified Gram-Schmidt against the orthonormal set
+    const std::vector<double>& d = ctx->resp[k].dir;
+    double c = 0.0;
+    for (int q = 0; q < nb; ++q) c += d[q] * rem[q];
+    for (int q = 0; q < nb; ++q) rem[q] -= c * d[q];
+    ra->c[k] = c;
+    ra->w[k] = ctx->resp[k].w;
+  }
+  double rn2 = 0.0;
+  for (int q = 0; q < nb; ++q) rn2 += rem[q] * rem[q];
+  if (rn2 > 1e-12 * nrm2 && nrm2 > 1e-18 * gn2 && ctx->resp.size() < static_cast<size_t>(MAXRESP)) {
+    const double rn = std::sqrt(rn2);
+    hf_ctx::BcResponse nr;
+    nr.dir.resize(nb);
+    for (int q = 0; q < nb; ++q) nr.dir[q] = rem[q] / rn;
+    const int rc = solve_response(ctx, nr.dir, max_it, &nr.w);
+    if (rc == HF_ERR_HIP) return rc;
+    if (rc == HF_OK) {
+      ra->c[ctx->resp.size()] = rn;
+      ra->w[ctx->resp.size()] = nr.w;
+      ctx->resp.push_back(std::move(nr));
+    } else {
+      ctx->start_kind = 1;   // the extra solve did not converge: keep plain extrapolation from here on
+    }
+  }
+  ra->k = static_cast<int>(ctx->resp.size());
+  return HF_OK;
+}
+
+// One time step to the boundary values g_host (n_bc doubles on the host).  Leaves iteration count /
+// residual in h_scal.
+int step_device(hf_ctx* ctx, const double* g_host, double rtol, double atol, int max_it) {
+  const int nb = ctx->nbc;
+  RespArgs ra{};
+  ra.k = 0;
+  const bool hist_ok = nb > 0 && ctx->extrapolate && ctx->have_prev && ctx->g_hist >= 2;
+  if (ctx->start_kind >= 2 && hist_ok) HF_TRY(prepare_response(ctx, g_host, max_it, &ra));
+  if (nb > 0) HF_HIP(hipMemcpyAsync(ctx->d_g, g_host, sizeof(double) * nb, hipMemcpyHostToDevice, ctx->stream));
   // b = M u^n   (assemble_vector, run_with_diamond.py:476); with a previous step available the same
   // pass writes the extrapolated start vector 2 u^n - u^{n-1}, and the three state buffers rotate
   if (ctx->extrapolate && ctx->have_prev) {
     launch_spmv<8>(ctx, ctx->d_M, ctx->d_u, ctx->d_b, nullptr, ctx->d_uprev, ctx->d_ustart);
     // u^{n-1} <- u^n, iterate <- start vector (copies, not pointer rotation: captured graphs hold d_u)
     HF_HIP(hipMemcpyAsync(ctx->d_uprev, ctx->d_u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
-    HF_HIP(hipMemcpyAsync(ctx->d_u, ctx->d_ustart, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (ra.k > 0)
+      hipLaunchKernelGGL(k_start_vector, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, ctx->d_ustart, ra, ctx->d_u);
+    else
+      HF_HIP(hipMemcpyAsync(ctx->d_u, ctx->d_ustart, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
   } else {
     launch_spmv<0>(ctx, ctx->d_M, ctx->d_u, ctx->d_b);
     if (ctx->extrapolate) {         // keep u^n for the next step
@@ -384,6 +465,11 @@ int step_device(hf_ctx* ctx, double rtol, double atol, int max_it) {
     ctx->amg_fallbacks += 1;
     int pred = 0;
     rc = pcg_solve(ctx, sys, false, rtol, atol, max_it, &pred);
+  }
+  if (rc == HF_OK && nb > 0) {   // boundary history for the next step's second difference
+    ctx->h_g1.swap(ctx->h_g0);
+    ctx->h_g0.assign(g_host, g_host + nb);
+    if (ctx->g_hist < 2) ctx->g_hist += 1;
   }
   return rc;
 }

@@ -21,7 +21,7 @@ K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS = range(6)
 
 EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_materials",
-    "hf_update_kappa", "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
+    "hf_update_kappa", "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_set_start_vector", "hf_get_response_solves", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
     "hf_flux_setup", "hf_flux_project", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
 
@@ -87,6 +87,8 @@ def load_library():
         "hf_set_dirichlet": [vp, i32, pi],
         "hf_assemble": [vp, dbl, i32],
         "hf_set_precond": [vp, i32, i32],
+        "hf_set_start_vector": [vp, i32],
+        "hf_get_response_solves": [vp, C.POINTER(i64)],
         "hf_get_amg_info": [vp, pi, pi, i32, pd, pd],
         "hf_get_amg_fallbacks": [vp, C.POINTER(i64)],
         "hf_set_state": [vp, pd],
@@ -204,6 +206,15 @@ class HeatflowHIP:
     def set_precond(self, kind=PC_JACOBI, reuse=False):
         """PC_JACOBI (0) or PC_AMG (1); call before assemble()."""
         self._check(self._lib.hf_set_precond(self._ctx, int(kind), 1 if reuse else 0))
+
+    def set_start_vector(self, kind=2):
+        """0: u^n, 1: 2u^n - u^{n-1}, 2 (default): that + response to the boundary values' second difference."""
+        self._check(self._lib.hf_set_start_vector(self._ctx, int(kind)))
+
+    def response_solves(self):
+        c = C.c_int64()
+        self._check(self._lib.hf_get_response_solves(self._ctx, C.byref(c)))
+        return int(c.value)
 
     def amg_info(self):
         nl, opc, secs = C.c_int32(), C.c_double(), C.c_double()

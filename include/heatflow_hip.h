@@ -111,6 +111,17 @@ int hf_set_precond(hf_ctx* ctx, int32_t kind, int32_t reuse);
 int hf_get_amg_info(hf_ctx* ctx, int32_t* n_levels, int32_t* level_rows, int32_t max_levels, double* op_complexity,
                     double* setup_seconds);
 
+/* Start vector of every hf_step / hf_run solve (the converged answer does not depend on it, only the
+ * iteration count does): kind 0 = u^n (what KSP.solve sees in the reference, run_with_diamond.py:480,
+ * where it is irrelevant because the solve is direct); 1 = 2 u^n - u^{n-1}; 2 (default) = that plus the
+ * response to the second difference of the boundary values: the loop is linear,
+ * u^{n+1} = T u^n + R g^{n+1}, so  u^{n+1} - 2u^n + u^{n-1} = T(...) + R (g^{n+1} - 2g^n + g^{n-1});  R d is
+ * obtained by one extra solve the first time a new direction d of that second difference appears (the
+ * heated line's Gaussian profile: once per assembled operator) and re-used, scaled, afterwards. */
+int hf_set_start_vector(hf_ctx* ctx, int32_t kind);
+/* Number of extra response solves spent so far (diagnostics). */
+int hf_get_response_solves(hf_ctx* ctx, int64_t* count);
+
 /* Number of hf_step solves that hit a breakdown (p.Ap <= 0) in the multigrid-preconditioned loop and
  * were finished with the Jacobi preconditioner instead (still on the GPU).  0 in every case tested. */
 int hf_get_amg_fallbacks(hf_ctx* ctx, int64_t* count);

@@ -621,3 +621,35 @@ def test_call_order_state_machine(hip, case_no_diamond_small):
         with pytest.raises(ValueError):
             be.sample([n])                                           # node out of range
         assert be.sample([5])[0] == 350.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precond", [0, 1])
+def test_start_vector_kinds_same_answer_fewer_iterations(hip, precond, case_with_diamond_small):
+    """hf_set_start_vector: the converged field does not depend on the start vector; the boundary-response
+    correction (kind 2) costs one extra solve per operator (the heated line's profile is the only direction
+    the second difference of the boundary values ever has) and needs fewer iterations than plain
+    extrapolation (kind 1), which needs fewer than starting from u^n (kind 0)."""
+    cfg, stack, mesh = case_with_diamond_small
+    nsteps = 40
+    out = {}
+    for kind in (0, 1, 2):
+        prob = make_problem(cfg, stack, mesh, precond=precond)
+        try:
+            prob.backend.set_start_vector(kind)
+            _, _, iters = prob.run(nsteps, time_varying=[prob.bcs[3]])
+            out[kind] = (prob.state(), int(np.sum(iters)), prob.backend.response_solves())
+        finally:
+            prob.close()
+    for kind in (1, 2):
+        assert np.abs(out[kind][0] - out[0][0]).max() <= 2e-5, kind
+    assert out[0][2] == 0 and out[1][2] == 0 and out[2][2] == 1
+    assert out[2][1] < out[1][1] <= out[0][1], {k: v[1] for k, v in out.items()}
+    if precond == 1:   # multigrid-PCG contracts at a fixed rate per iteration: a 30x smaller start residual shows
+        assert out[2][1] <= 0.95 * out[1][1], {k: v[1] for k, v in out.items()}
+    prob2 = make_problem(cfg, stack, mesh, precond=precond)
+    try:
+        with pytest.raises(ValueError):
+            prob2.backend.set_start_vector(3)
+    finally:
+        prob2.close()
