@@ -206,6 +206,10 @@ def main():
             (("spmv", hb.K_PCG_SPMV), ("update", hb.K_PCG_UPDATE), ("plain_spmv", hb.K_SPMV))}
     spmv_us = k_us["spmv"]
     achieved = spmv_bytes / (spmv_us * 1e-6) / 1e9
+    # the device's own read ceiling on this operator's arrays ("measured device bandwidth on the box
+    # alongside the nominal 8 TB/s"): a plain 16-byte-load streaming read of values + column indices, 12*nnz bytes
+    read_us = 1e3 * be.time_kernel(hb.K_STREAM_READ, 100)
+    stream_gbs = 12 * nnz / (read_us * 1e-6) / 1e9
     # HBM traffic of that kernel from the PMC passes kept under profiles/ (rocprofv3 cannot wrap itself):
     # only quoted when it was collected on exactly this matrix
     traffic = None
@@ -252,7 +256,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<9> (PCG iteration head: CSR SpMV with the direction update p, Ap fused)",
                          "bytes_per_launch": spmv_bytes, "us_per_launch": spmv_us,
-                         "us_per_launch_in_loop_events": spmv_us_loop, "us_back_to_back": k_us},
+                         "us_per_launch_in_loop_events": spmv_us_loop, "us_back_to_back": k_us,
+                         "measured_stream_read": {"GB/s": stream_gbs, "us": read_us, "bytes": 12 * nnz,
+                                                  "what": "16-byte-load read of the operator's values + column indices on this box",
+                                                  "frac_of_it": achieved / stream_gbs,
+                                                  "plain_spmv_frac_of_it": (12 * nnz + 20 * n) / (k_us["plain_spmv"] * 1e-6) / 1e9 / stream_gbs}},
         }
         if precond == 1:
             out["config"]["amg"] = amg_info

@@ -506,6 +506,11 @@ int hf_time_kernel(hf_ctx* ctx, int32_t which, int32_t reps, double* ms_avg) {
         case HF_K_PCG_DIR:
           return fail(ctx, HF_ERR_ARG, "HF_K_PCG_DIR: the direction update is fused into the PCG SpMV (HF_K_PCG_SPMV)");
         case HF_K_ASSEMBLE: HF_TRY(launch_assemble(ctx)); break;
+        case HF_K_STREAM_READ:
+          hipLaunchKernelGGL(k_stream_read, dim3(MAXP), dim3(TS), 0, ctx->stream, static_cast<size_t>(ctx->nnz) / 2,
+                             reinterpret_cast<const double2*>(ctx->d_A), static_cast<size_t>(ctx->nnz) / 4,
+                             reinterpret_cast<const double2*>(ctx->d_colidx), ctx->d_tmp);
+          break;
         default: return fail(ctx, HF_ERR_ARG, "hf_time_kernel: unknown kernel %d", which);
       }
     }

@@ -68,7 +68,9 @@ enum {
   HF_K_PCG_UPDATE = 2,  /* x += a p; r -= a Ap; z = D^-1 r; r.z, z.z    */
   HF_K_PCG_DIR = 3,     /* retired: the direction update is fused into HF_K_PCG_SPMV (returns HF_ERR_ARG) */
   HF_K_ASSEMBLE = 4,    /* element kernel in the mode of the last hf_assemble */
-  HF_K_RHS = 5          /* b = M u^n                                    */
+  HF_K_RHS = 5,         /* b = M u^n                                    */
+  HF_K_STREAM_READ = 6  /* plain streaming read of the operator's values + column indices (12 nnz bytes, 16-byte loads):
+                           the read bandwidth this device reaches on the SpMV's own arrays - its practical ceiling */
 };
 
 const char* hf_version(void);
