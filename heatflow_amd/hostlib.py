@@ -1,0 +1,71 @@
+"""ctypes binding of libheatflow_host.so (include/heatflow_host.h): host-only native helpers of the mesh
+layer.  Plain C built with gcc - no GPU involved; `available()` is False when it cannot be built, and the
+callers keep a (slow) numpy path for that case, which is I/O plumbing, not the compute path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libheatflow_host.so")
+EXPORTS = ["hfh_version", "hfh_write_msh22"]
+
+_lib = None
+_failed = False
+
+
+def build_library(force=False):
+    src = os.path.join(_HERE, "csrc", "host", "heatflow_host.c")
+    hdr = os.path.join(_HERE, "..", "include", "heatflow_host.h")
+    if not force and os.path.isfile(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return LIB_PATH
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "libheatflow_host.so"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libheatflow_host.so failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+def load_library():
+    global _lib, _failed
+    if _lib is not None:
+        return _lib
+    if _failed:
+        return None
+    try:
+        lib = C.CDLL(build_library())
+    except (OSError, RuntimeError):
+        _failed = True
+        return None
+    i32 = C.c_int32
+    lib.hfh_version.restype = C.c_int
+    lib.hfh_write_msh22.restype = C.c_int
+    lib.hfh_write_msh22.argtypes = [C.c_char_p, i32, i32, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(i32), i32,
+                                    C.POINTER(C.c_char_p), C.POINTER(i32)]
+    _lib = lib
+    return lib
+
+
+def available():
+    return load_library() is not None
+
+
+def write_msh22(filename, coords, tris, tags, names=None):
+    """MSH 2.2 ASCII through the native writer (see heatflow_host.h)."""
+    lib = load_library()
+    if lib is None:
+        raise RuntimeError("libheatflow_host.so is not available")
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    tris = np.ascontiguousarray(tris, dtype=np.int32)
+    tags = np.ascontiguousarray(tags, dtype=np.int32)
+    items = sorted((names or {}).items(), key=lambda kv: kv[1])
+    nm = (C.c_char_p * max(len(items), 1))(*[k.encode() for k, _ in items])
+    nt = np.array([t for _, t in items] or [0], dtype=np.int32)
+    rc = lib.hfh_write_msh22(os.fsencode(filename), len(coords), len(tris), coords.ctypes.data_as(C.POINTER(C.c_double)),
+                             tris.ctypes.data_as(C.POINTER(C.c_int32)), tags.ctypes.data_as(C.POINTER(C.c_int32)),
+                             len(items), nm, nt.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise OSError(-rc, os.strerror(-rc), filename)

