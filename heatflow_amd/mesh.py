@@ -432,25 +432,54 @@ def read_msh(filename):
     raise MeshError(f"{filename}: unsupported MSH version {fmt[:1]} (2.2 and 4.1 ASCII are read)")
 
 
+def _numbers(block, dtype=np.float64):
+    """All whitespace-separated numbers of a list of lines, parsed by numpy's C tokenizer."""
+    return np.fromstring(" ".join(block), dtype=dtype, sep=" ")
+
+
 def _read_msh2(lines, pos):
     k = pos["$Nodes"]
     n = int(lines[k + 1])
-    nodes = np.loadtxt(lines[k + 2:k + 2 + n], ndmin=2)
+    nodes = _numbers(lines[k + 2:k + 2 + n])
+    if nodes.size != 4 * n:
+        raise MeshError("MSH 2.2 $Nodes: expected 4 numbers per line")
+    nodes = nodes.reshape(n, 4)
     ids = nodes[:, 0].astype(np.int64)
     remap = np.full(ids.max() + 1, -1, dtype=np.int64)
     remap[ids] = np.arange(n)
     k = pos["$Elements"]
     ne = int(lines[k + 1])
-    tris, tags = [], []
-    for ln in lines[k + 2:k + 2 + ne]:
-        p = ln.split()
-        if int(p[1]) != 2:
-            continue  # points / lines that gmsh also stores
-        ntag = int(p[2])
-        tags.append(int(p[3]) if ntag else 0)
-        tris.append([int(v) for v in p[3 + ntag:3 + ntag + 3]])
-    tris = remap[np.array(tris, dtype=np.int64)].astype(np.int32)
-    return nodes[:, 1:3].copy(), tris, np.array(tags, dtype=np.int32)
+    block = lines[k + 2:k + 2 + ne]
+    # gmsh stores points and lines before the triangles; skip them, then try the uniform fast path
+    first = 0
+    while first < ne and int(block[first].split()[1]) != 2:
+        first += 1
+    tri_rows = None
+    if first < ne:
+        ncol = len(block[first].split())
+        flat = _numbers(block[first:], dtype=np.int64)
+        if flat.size == ncol * (ne - first):
+            rows = flat.reshape(ne - first, ncol)
+            if (rows[:, 1] == 2).all() and (rows[:, 2] == rows[0, 2]).all():
+                tri_rows = rows
+    if tri_rows is not None:
+        ntag = int(tri_rows[0, 2])
+        tags = tri_rows[:, 3] if ntag else np.zeros(len(tri_rows), dtype=np.int64)
+        tris = tri_rows[:, 3 + ntag:3 + ntag + 3]
+    else:                                          # mixed element types / tag counts: line by line
+        tris, tags = [], []
+        for ln in block:
+            p = ln.split()
+            if int(p[1]) != 2:
+                continue
+            ntag = int(p[2])
+            tags.append(int(p[3]) if ntag else 0)
+            tris.append([int(v) for v in p[3 + ntag:3 + ntag + 3]])
+        tris = np.array(tris, dtype=np.int64).reshape(-1, 3)
+    if len(tris) == 0:
+        raise MeshError("no 3-node triangles in the MSH 2.2 file")
+    tris = remap[np.asarray(tris, dtype=np.int64)].astype(np.int32)
+    return nodes[:, 1:3].copy(), tris, np.asarray(tags, dtype=np.int32)
 
 
 def _read_msh41(lines, pos):
@@ -474,11 +503,14 @@ def _read_msh41(lines, pos):
     for _ in range(nblocks):
         _dim, _tag, parametric, nb = (int(v) for v in lines[k].split())
         k += 1
-        ids[at:at + nb] = [int(v) for v in lines[k:k + nb]]
-        k += nb
-        for q in range(nb):
-            xyz[at + q] = [float(v) for v in lines[k + q].split()[:3]]
-        k += nb
+        if nb:
+            ids[at:at + nb] = _numbers(lines[k:k + nb], dtype=np.int64)
+            k += nb
+            vals = _numbers(lines[k:k + nb])
+            if vals.size % nb:
+                raise MeshError("MSH 4.1 $Nodes: ragged coordinate block")
+            xyz[at:at + nb] = vals.reshape(nb, -1)[:, :3]     # parametric blocks carry extra columns
+            k += nb
         at += nb
     remap = np.full(ids.max() + 1, -1, dtype=np.int64)
     remap[ids] = np.arange(nnodes)
@@ -489,20 +521,21 @@ def _read_msh41(lines, pos):
     for _ in range(nblocks):
         dim, etag, etype, nb = (int(v) for v in lines[k].split())
         k += 1
-        if dim == 2 and etype == 2:
-            tag = surf_phys.get(etag, etag)
-            for ln in lines[k:k + nb]:
-                p = ln.split()
-                tris.append([int(p[1]), int(p[2]), int(p[3])])
-                tags.append(tag)
+        if dim == 2 and etype == 2 and nb:
+            rows = _numbers(lines[k:k + nb], dtype=np.int64)
+            if rows.size != 4 * nb:
+                raise MeshError("MSH 4.1 $Elements: a 3-node triangle line must hold 4 integers")
+            tris.append(rows.reshape(nb, 4)[:, 1:4])
+            tags.append(np.full(nb, surf_phys.get(etag, etag), dtype=np.int64))
         k += nb
     if not tris:
         raise MeshError("no 3-node triangles in the MSH 4.1 file")
-    tris = remap[np.array(tris, dtype=np.int64)]
+    tris = remap[np.concatenate(tris)]
+    tags = np.concatenate(tags)
     used = np.unique(tris)                       # gmsh may store nodes that only points/curves use
     compact = np.full(nnodes, -1, dtype=np.int64)
     compact[used] = np.arange(len(used))
-    return xyz[used, :2].copy(), compact[tris].astype(np.int32), np.array(tags, dtype=np.int32)
+    return xyz[used, :2].copy(), compact[tris].astype(np.int32), tags.astype(np.int32)
 
 
 def reorder_mesh(coords, tris, tags):
