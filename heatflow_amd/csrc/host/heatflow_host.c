@@ -59,3 +59,171 @@ int hfh_write_msh22(const char* path, int32_t n, int32_t ne, const double* coord
   if (fclose(f) != 0 && rc == 0) rc = -EIO;
   return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Quadtree level map of the mesher (heatflow_amd/mesh.py Mesh.build_mesh holds the same algorithm in
+ * numpy; tests compare the two).  Dense int8 maps over the padded base grid, row-major [nzp][nrp],
+ * nzp and nrp multiples of 2^lmax.
+ * ------------------------------------------------------------------------------------------------ */
+
+typedef struct { int8_t* p; int32_t nz, nr; } grid8;
+
+static int grid_alloc(grid8* g, int32_t nz, int32_t nr) {
+  g->nz = nz; g->nr = nr;
+  g->p = (int8_t*)malloc((size_t)nz * (size_t)nr > 0 ? (size_t)nz * (size_t)nr : 1);
+  return g->p ? 0 : -ENOMEM;
+}
+
+static inline int8_t min4(int8_t a, int8_t b, int8_t c, int8_t d) { int8_t m = a < b ? a : b; int8_t n = c < d ? c : d; return m < n ? m : n; }
+static inline int8_t max4(int8_t a, int8_t b, int8_t c, int8_t d) { int8_t m = a > b ? a : b; int8_t n = c > d ? c : d; return m > n ? m : n; }
+
+/* 2x2 block minimum / maximum of src into dst (dst is half the size) */
+static void reduce_min(const grid8* s, grid8* d) {
+  for (int32_t i = 0; i < d->nz; ++i) {
+    const int8_t* r0 = s->p + (size_t)(2 * i) * s->nr; const int8_t* r1 = r0 + s->nr; int8_t* o = d->p + (size_t)i * d->nr;
+    for (int32_t j = 0; j < d->nr; ++j) o[j] = min4(r0[2 * j], r0[2 * j + 1], r1[2 * j], r1[2 * j + 1]);
+  }
+}
+static void reduce_max(const grid8* s, grid8* d) {
+  for (int32_t i = 0; i < d->nz; ++i) {
+    const int8_t* r0 = s->p + (size_t)(2 * i) * s->nr; const int8_t* r1 = r0 + s->nr; int8_t* o = d->p + (size_t)i * d->nr;
+    for (int32_t j = 0; j < d->nr; ++j) o[j] = max4(r0[2 * j], r0[2 * j + 1], r1[2 * j], r1[2 * j + 1]);
+  }
+}
+
+int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* mat, const int8_t* allowed, int8_t* level) {
+  if (nzp <= 0 || nrp <= 0 || lmax < 0 || lmax > 30 || !mat || !allowed || !level) return -EINVAL;
+  if ((nzp & ((1 << lmax) - 1)) || (nrp & ((1 << lmax) - 1))) return -EINVAL;
+  const size_t N = (size_t)nzp * (size_t)nrp;
+  int rc = 0;
+  /* ---- admissibility per level: one material (>= 0) and allowed >= lv over the aligned block ---- */
+  grid8* ok = (grid8*)calloc((size_t)lmax + 1, sizeof(grid8));       /* ok[lv].p: 1 / 0, lv = 1..top */
+  if (!ok) return -ENOMEM;
+  int top = 0;
+  {
+    grid8 amin = {0}, mmin = {0}, mmax = {0};
+    const grid8 a0 = {(int8_t*)allowed, nzp, nrp}, m0 = {(int8_t*)mat, nzp, nrp};
+    const grid8 *pa = &a0, *pmin = &m0, *pmax = &m0;
+    for (int lv = 1; lv <= lmax && rc == 0; ++lv) {
+      grid8 na, nmin, nmax;
+      const int32_t hz = nzp >> lv, hr = nrp >> lv;
+      if (grid_alloc(&na, hz, hr) || grid_alloc(&nmin, hz, hr) || grid_alloc(&nmax, hz, hr) || grid_alloc(&ok[lv], hz, hr)) { rc = -ENOMEM; free(na.p); free(nmin.p); free(nmax.p); break; }
+      reduce_min(pa, &na); reduce_min(pmin, &nmin); reduce_max(pmax, &nmax);
+      int any = 0;
+      const size_t M = (size_t)hz * hr;
+      for (size_t q = 0; q < M; ++q) {
+        const int8_t v = (int8_t)(nmin.p[q] == nmax.p[q] && nmin.p[q] >= 0 && na.p[q] >= lv);
+        ok[lv].p[q] = v; any |= v;
+      }
+      free(amin.p); free(mmin.p); free(mmax.p);
+      amin = na; mmin = nmin; mmax = nmax; pa = &amin; pmin = &mmin; pmax = &mmax;
+      if (!any) { free(ok[lv].p); ok[lv].p = NULL; break; }
+      top = lv;
+    }
+    free(amin.p); free(mmin.p); free(mmax.p);
+  }
+  /* ---- a cell's level = the highest admissible block above it: top-down ---- */
+  if (rc == 0) {
+    grid8 cur = {0};
+    for (int lv = top; lv >= 1 && rc == 0; --lv) {     /* cur: assigned level (or -1) on the grid of level lv */
+      grid8 nxt;
+      if (grid_alloc(&nxt, nzp >> lv, nrp >> lv)) { rc = -ENOMEM; break; }
+      for (int32_t i = 0; i < nxt.nz; ++i)
+        for (int32_t j = 0; j < nxt.nr; ++j) {
+          const int8_t par = cur.p ? cur.p[(size_t)(i >> 1) * cur.nr + (j >> 1)] : (int8_t)-1;
+          nxt.p[(size_t)i * nxt.nr + j] = par >= 0 ? par : (ok[lv].p[(size_t)i * nxt.nr + j] ? (int8_t)lv : (int8_t)-1);
+        }
+      free(cur.p);
+      cur = nxt;
+    }
+    if (rc == 0)
+      for (int32_t i = 0; i < nzp; ++i)
+        for (int32_t j = 0; j < nrp; ++j) {
+          const int8_t par = cur.p ? cur.p[(size_t)(i >> 1) * cur.nr + (j >> 1)] : (int8_t)-1;
+          level[(size_t)i * nrp + j] = par >= 0 ? par : (mat[(size_t)i * nrp + j] >= 0 ? (int8_t)0 : (int8_t)-1);
+        }
+    free(cur.p);
+  }
+  for (int lv = 0; lv <= lmax; ++lv) free(ok[lv].p);
+  free(ok);
+  if (rc) return rc;
+  /* ---- 2:1 balance with smooth grading: a level-L leaf needs each of its 8 same-size neighbour blocks to
+   * hold nothing finer than L-1.  Each sweep walks the levels upwards on a min-pyramid that is patched as
+   * blocks are demoted; downward ripples take another sweep. ---- */
+  const int8_t BIG = 127;
+  grid8* pyr = (grid8*)calloc((size_t)lmax + 1, sizeof(grid8));
+  if (!pyr) return -ENOMEM;
+  for (int lv = 0; lv <= lmax; ++lv)
+    if (grid_alloc(&pyr[lv], nzp >> lv, nrp >> lv)) rc = -ENOMEM;
+  /* the min-pyramid is built once and kept consistent: a demotion rewrites its block on every finer level, the
+   * coarser levels are re-reduced on the way up (levels 0 and 1 never change a decision, so a sweep costs N/4) */
+  if (rc == 0) {
+    for (size_t q = 0; q < N; ++q) pyr[0].p[q] = level[q] < 0 ? BIG : level[q];
+    if (lmax >= 1) reduce_min(&pyr[0], &pyr[1]);
+  }
+  int converged = 0;
+  for (int sweep = 0; sweep < 2 * (lmax + 2) && rc == 0; ++sweep) {
+    int changed = 0;
+    for (int lv = 2; lv <= lmax; ++lv) {
+      reduce_min(&pyr[lv - 1], &pyr[lv]);
+      grid8* g = &pyr[lv];
+      /* demotions of one level are decided on the unpatched map of that level (as the vectorised original does) */
+      size_t ndem = 0, cap = 0; int32_t* dem = NULL;
+      for (int32_t i = 0; i < g->nz; ++i)
+        for (int32_t j = 0; j < g->nr; ++j) {
+          if (g->p[(size_t)i * g->nr + j] != lv) continue;
+          int8_t m = BIG;
+          for (int di = -1; di <= 1; ++di) {
+            const int32_t a = i + di; if (a < 0 || a >= g->nz) continue;
+            for (int dj = -1; dj <= 1; ++dj) {
+              const int32_t b = j + dj; if (b < 0 || b >= g->nr || (di == 0 && dj == 0)) continue;
+              const int8_t v = g->p[(size_t)a * g->nr + b]; if (v < m) m = v;
+            }
+          }
+          if (m < lv - 1) {
+            if (ndem == cap) { cap = cap ? 2 * cap : 1024; int32_t* t = (int32_t*)realloc(dem, cap * 2 * sizeof(int32_t)); if (!t) { rc = -ENOMEM; break; } dem = t; }
+            dem[2 * ndem] = i; dem[2 * ndem + 1] = j; ++ndem;
+          }
+        }
+      for (size_t q = 0; q < ndem && rc == 0; ++q) {
+        const int32_t i = dem[2 * q], j = dem[2 * q + 1];
+        g->p[(size_t)i * g->nr + j] = (int8_t)(lv - 1);
+        for (int l = 0; l < lv; ++l) {              /* the block on the finer pyramid levels and in the level map */
+          const int32_t s = 1 << (lv - l);
+          grid8* f = &pyr[l];
+          for (int32_t a = i * s; a < (i + 1) * s; ++a) memset(f->p + (size_t)a * f->nr + (size_t)j * s, lv - 1, (size_t)s);
+        }
+        const int32_t s0 = 1 << lv;
+        for (int32_t a = i * s0; a < (i + 1) * s0; ++a) memset(level + (size_t)a * nrp + (size_t)j * s0, lv - 1, (size_t)s0);
+        changed = 1;
+      }
+      free(dem);
+      if (rc) break;
+    }
+    if (!changed) { converged = 1; break; }
+  }
+  for (int lv = 0; lv <= lmax; ++lv) free(pyr[lv].p);
+  free(pyr);
+  if (rc) return rc;
+  return converged ? 0 : -EDOM;
+}
+
+/* Leaves of the level map in the mesher's order: by level, row-major within a level.  Writes up to `cap`
+ * (i0, j0, lev) triples and returns the total count (call with cap = 0 to size the arrays). */
+int64_t hfh_quadtree_leaves(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* level, int64_t cap, int64_t* i0,
+                            int64_t* j0, int64_t* lev) {
+  if (nzp <= 0 || nrp <= 0 || lmax < 0 || lmax > 30 || !level) return -EINVAL;
+  int64_t cnt = 0;
+  for (int lv = 0; lv <= lmax; ++lv) {
+    const int32_t hz = nzp >> lv, hr = nrp >> lv;
+    for (int32_t i = 0; i < hz; ++i) {
+      const int8_t* row = level + ((size_t)i << lv) * nrp;
+      for (int32_t j = 0; j < hr; ++j)
+        if (row[(size_t)j << lv] == lv) {
+          if (cnt < cap) { i0[cnt] = (int64_t)i << lv; j0[cnt] = (int64_t)j << lv; lev[cnt] = lv; }
+          ++cnt;
+        }
+    }
+  }
+  return cnt;
+}

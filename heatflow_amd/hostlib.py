@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libheatflow_host.so")
-EXPORTS = ["hfh_version", "hfh_write_msh22"]
+EXPORTS = ["hfh_version", "hfh_write_msh22", "hfh_quadtree_levels", "hfh_quadtree_leaves"]
 
 _lib = None
 _failed = False
@@ -45,6 +45,11 @@ def load_library():
     lib.hfh_write_msh22.restype = C.c_int
     lib.hfh_write_msh22.argtypes = [C.c_char_p, i32, i32, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(i32), i32,
                                     C.POINTER(C.c_char_p), C.POINTER(i32)]
+    p8, p64 = C.POINTER(C.c_int8), C.POINTER(C.c_int64)
+    lib.hfh_quadtree_levels.restype = C.c_int
+    lib.hfh_quadtree_levels.argtypes = [i32, i32, i32, p8, p8, p8]
+    lib.hfh_quadtree_leaves.restype = C.c_int64
+    lib.hfh_quadtree_leaves.argtypes = [i32, i32, i32, p8, C.c_int64, p64, p64, p64]
     _lib = lib
     return lib
 
@@ -69,3 +74,35 @@ def write_msh22(filename, coords, tris, tags, names=None):
                              len(items), nm, nt.ctypes.data_as(C.POINTER(C.c_int32)))
     if rc != 0:
         raise OSError(-rc, os.strerror(-rc), filename)
+
+
+def quadtree_levels(mat, allowed, lmax):
+    """Balanced quadtree level map (int8, -1 outside) from the material / allowed-level maps (heatflow_host.h)."""
+    lib = load_library()
+    if lib is None:
+        raise RuntimeError("libheatflow_host.so is not available")
+    mat = np.ascontiguousarray(mat, dtype=np.int8)
+    allowed = np.ascontiguousarray(allowed, dtype=np.int8)
+    level = np.empty(mat.shape, dtype=np.int8)
+    p8 = C.POINTER(C.c_int8)
+    rc = lib.hfh_quadtree_levels(mat.shape[0], mat.shape[1], int(lmax), mat.ctypes.data_as(p8), allowed.ctypes.data_as(p8),
+                                 level.ctypes.data_as(p8))
+    if rc != 0:
+        raise RuntimeError(f"hfh_quadtree_levels failed ({os.strerror(-rc)})")
+    return level
+
+
+def quadtree_leaves(level, lmax):
+    """(i0, j0, lev) int64 arrays of the leaves of a level map, by level and row-major within a level."""
+    lib = load_library()
+    if lib is None:
+        raise RuntimeError("libheatflow_host.so is not available")
+    level = np.ascontiguousarray(level, dtype=np.int8)
+    p8, p64 = C.POINTER(C.c_int8), C.POINTER(C.c_int64)
+    n = lib.hfh_quadtree_leaves(level.shape[0], level.shape[1], int(lmax), level.ctypes.data_as(p8), 0, None, None, None)
+    if n < 0:
+        raise RuntimeError(f"hfh_quadtree_leaves failed ({os.strerror(-n)})")
+    i0, j0, lev = (np.empty(n, dtype=np.int64) for _ in range(3))
+    lib.hfh_quadtree_leaves(level.shape[0], level.shape[1], int(lmax), level.ctypes.data_as(p8), n, i0.ctypes.data_as(p64),
+                            j0.ctypes.data_as(p64), lev.ctypes.data_as(p64))
+    return i0, j0, lev

@@ -147,59 +147,9 @@ class Mesh:
             starts.append(idx)
         return np.concatenate(lines), np.array(starts, dtype=np.int64)
 
-    def build_mesh(self, verbose=False):
-        mats = self.materials
-        if not mats:
-            raise MeshError("no materials")
-        for m in mats:
-            if m.mesh_size is None or m.mesh_size <= 0:
-                raise MeshError(f"{m.name}: mesh_size required")
-        self._check_mesh(self.boundaries)
-
-        zb = _unique_breaks([v for m in mats for v in m.boundaries[:2]])
-        rb = _unique_breaks([v for m in mats for v in m.boundaries[2:]])
-        h0 = min(m.mesh_size for m in mats)
-
-        def slab_sizes(breaks, lo, hi):
-            out = []
-            for k in range(len(breaks) - 1):
-                mid = 0.5 * (breaks[k] + breaks[k + 1])
-                hs = [m.mesh_size for m in mats if m.boundaries[lo] < mid < m.boundaries[hi]]
-                out.append(min(hs) if hs else h0)
-            return out
-
-        zc, zs = self._axis(zb, slab_sizes(zb, 0, 1), h0)
-        rc, rs = self._axis(rb, slab_sizes(rb, 2, 3), h0)
-        nz, nr = len(zc) - 1, len(rc) - 1
-        dz, dr = np.diff(zc), np.diff(rc)
-
-        # material / allowed-level maps, filled per (z-slab, r-slab) rectangle
-        lmax = 0
-        blocks = []
-        for a in range(len(zb) - 1):
-            zm = 0.5 * (zb[a] + zb[a + 1])
-            for b in range(len(rb) - 1):
-                rm = 0.5 * (rb[b] + rb[b + 1])
-                owner = [k for k, m in enumerate(mats) if m.boundaries[0] < zm < m.boundaries[1]
-                         and m.boundaries[2] < rm < m.boundaries[3]]
-                if len(owner) > 1:
-                    raise MeshError(f"materials {[mats[k].name for k in owner]} overlap")
-                if not owner:
-                    continue
-                k = owner[0]
-                cell = max(dz[zs[a]:zs[a + 1]].max(), dr[rs[b]:rs[b + 1]].max())
-                lev = int(math.floor(math.log2(mats[k].mesh_size / cell) + 1e-9))
-                lev = max(0, min(lev, self.MAX_LEVEL))
-                lmax = max(lmax, lev)
-                blocks.append((a, b, k, lev))
-        pad = 1 << lmax
-        nzp, nrp = _roundup(nz, pad), _roundup(nr, pad)
-        mat = np.full((nzp, nrp), -1, dtype=np.int8)
-        allowed = np.zeros((nzp, nrp), dtype=np.int8)
-        for a, b, k, lev in blocks:
-            mat[zs[a]:zs[a + 1], rs[b]:rs[b + 1]] = k
-            allowed[zs[a]:zs[a + 1], rs[b]:rs[b + 1]] = lev
-
+    @staticmethod
+    def _quadtree_numpy(mat, allowed, lmax, nzp, nrp):
+        """Level map + leaves in numpy: the steps hfh_quadtree_levels / hfh_quadtree_leaves restate in C."""
         # ---- initial levels: largest aligned block that is one material and small enough
         # "block of level lv is admissible" is monotone (an admissible block has admissible children), so a
         # cell's level is the highest admissible block above it: collect the maps bottom-up, assign top-down
@@ -268,10 +218,75 @@ class Mesh:
         i0 = np.concatenate(li)
         j0 = np.concatenate(lj)
         lev = np.concatenate(ll)
+        return i0, j0, lev
+
+    def build_mesh(self, verbose=False, use_native=None):
+        mats = self.materials
+        if not mats:
+            raise MeshError("no materials")
+        for m in mats:
+            if m.mesh_size is None or m.mesh_size <= 0:
+                raise MeshError(f"{m.name}: mesh_size required")
+        self._check_mesh(self.boundaries)
+
+        zb = _unique_breaks([v for m in mats for v in m.boundaries[:2]])
+        rb = _unique_breaks([v for m in mats for v in m.boundaries[2:]])
+        h0 = min(m.mesh_size for m in mats)
+
+        def slab_sizes(breaks, lo, hi):
+            out = []
+            for k in range(len(breaks) - 1):
+                mid = 0.5 * (breaks[k] + breaks[k + 1])
+                hs = [m.mesh_size for m in mats if m.boundaries[lo] < mid < m.boundaries[hi]]
+                out.append(min(hs) if hs else h0)
+            return out
+
+        zc, zs = self._axis(zb, slab_sizes(zb, 0, 1), h0)
+        rc, rs = self._axis(rb, slab_sizes(rb, 2, 3), h0)
+        nz, nr = len(zc) - 1, len(rc) - 1
+        dz, dr = np.diff(zc), np.diff(rc)
+
+        # material / allowed-level maps, filled per (z-slab, r-slab) rectangle
+        lmax = 0
+        blocks = []
+        for a in range(len(zb) - 1):
+            zm = 0.5 * (zb[a] + zb[a + 1])
+            for b in range(len(rb) - 1):
+                rm = 0.5 * (rb[b] + rb[b + 1])
+                owner = [k for k, m in enumerate(mats) if m.boundaries[0] < zm < m.boundaries[1]
+                         and m.boundaries[2] < rm < m.boundaries[3]]
+                if len(owner) > 1:
+                    raise MeshError(f"materials {[mats[k].name for k in owner]} overlap")
+                if not owner:
+                    continue
+                k = owner[0]
+                cell = max(dz[zs[a]:zs[a + 1]].max(), dr[rs[b]:rs[b + 1]].max())
+                lev = int(math.floor(math.log2(mats[k].mesh_size / cell) + 1e-9))
+                lev = max(0, min(lev, self.MAX_LEVEL))
+                lmax = max(lmax, lev)
+                blocks.append((a, b, k, lev))
+        pad = 1 << lmax
+        nzp, nrp = _roundup(nz, pad), _roundup(nr, pad)
+        mat = np.full((nzp, nrp), -1, dtype=np.int8)
+        allowed = np.zeros((nzp, nrp), dtype=np.int8)
+        for a, b, k, lev in blocks:
+            mat[zs[a]:zs[a + 1], rs[b]:rs[b + 1]] = k
+            allowed[zs[a]:zs[a + 1], rs[b]:rs[b + 1]] = lev
+
+        # ---- quadtree: initial levels, 2:1 balance, leaves.  Dense passes over the base grid (98 M cells for a
+        # 1 M-node mesh): native (libheatflow_host.so) when available, else the numpy statement of the same steps.
+        from . import hostlib
+
+        if use_native is None:
+            use_native = hostlib.available()
+        if use_native:
+            i0, j0, lev = hostlib.quadtree_leaves(hostlib.quadtree_levels(mat, allowed, lmax), lmax)
+        else:
+            i0, j0, lev = self._quadtree_numpy(mat, allowed, lmax, nzp, nrp)
         size = np.int64(1) << lev
         i1, j1 = i0 + size, j0 + size
         leaf_mat = mat[i0, j0].astype(np.int32)
-        del level, pyr, top, mat
+        del mat, allowed
 
         stride = np.int64(nrp + 1)
 

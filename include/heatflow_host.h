@@ -23,6 +23,17 @@ int hfh_version(void);
 int hfh_write_msh22(const char* path, int32_t n, int32_t ne, const double* coords, const int32_t* tris,
                     const int32_t* tags, int32_t n_names, const char* const* names, const int32_t* name_tags);
 
+/* Quadtree level map of the built-in mesher (replaces the gmsh size field + meshing of mesh.py:81-149; the numpy
+ * statement of the same algorithm stays in heatflow_amd/mesh.py and is compared in the tests).  mat / allowed /
+ * level: int8 maps over the padded base grid, row-major [nzp][nrp], nzp and nrp multiples of 2^lmax; mat < 0 =
+ * outside every material.  level[c] becomes the quadtree level of the leaf holding base cell c (-1 outside): the
+ * largest aligned block that is one material and no coarser than allowed, then 2:1-balanced with smooth grading.
+ * Returns -EDOM if the balance does not settle. */
+int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* mat, const int8_t* allowed, int8_t* level);
+/* Leaves of a level map, ordered by level and row-major within a level: writes up to cap triples, returns the count. */
+int64_t hfh_quadtree_leaves(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* level, int64_t cap, int64_t* i0,
+                            int64_t* j0, int64_t* lev);
+
 #ifdef __cplusplus
 }
 #endif

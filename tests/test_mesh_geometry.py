@@ -249,6 +249,10 @@ def test_mesher_on_random_layer_stacks(seed):
         mats.append(Material("ring", [z[0], z[-1], r_in, r_in * rng.uniform(1.5, 4.0)], {"k": 1.0, "rho_cv": 1.0},
                              float(max(m.mesh_size for m in mats) * rng.uniform(2.0, 30.0))))
     mesh = Mesh("m", [z[0], z[-1], 0.0, max(m.boundaries[3] for m in mats)], mats).build_mesh()
+    # the native quadtree passes (libheatflow_host.so) and their numpy statement give the same mesh, bit for bit
+    other = Mesh("m", [z[0], z[-1], 0.0, max(m.boundaries[3] for m in mats)], mats).build_mesh(use_native=False)
+    assert np.array_equal(mesh.coords, other.coords) and np.array_equal(mesh.tris, other.tris)
+    assert np.array_equal(mesh.tags, other.tags)
     c, t = mesh.coords, mesh.tris
     p0, p1, p2 = c[t[:, 0]], c[t[:, 1]], c[t[:, 2]]
     area = 0.5 * ((p1[:, 0] - p0[:, 0]) * (p2[:, 1] - p0[:, 1]) - (p2[:, 0] - p0[:, 0]) * (p1[:, 1] - p0[:, 1]))
@@ -283,3 +287,15 @@ def test_reorder_mesh_is_a_consistent_renumbering():
     # locality: mean |node index spread| inside a triangle shrinks by a large factor
     spread = lambda t: np.mean(t.max(axis=1) - t.min(axis=1))
     assert spread(t2) < 0.1 * spread(t_s)
+
+
+@pytest.mark.parametrize("name,scale", [("geballe_with_diamond", 2.0), ("geballe_no_diamond", 2.0), ("geballe_with_diamond", 8.0)])
+def test_native_and_numpy_quadtree_agree_on_the_reference_stacks(name, scale):
+    from heatflow_amd import hostlib
+    from heatflow_amd.geometry import build_stack, scale_mesh_sizes
+
+    assert hostlib.available(), "gcc is part of the image: libheatflow_host.so must build"
+    stack = build_stack(scale_mesh_sizes(load_cfg(name), scale))
+    a = Mesh("a", stack.bounds, stack.materials).build_mesh(use_native=True)
+    b = Mesh("b", stack.bounds, stack.materials).build_mesh(use_native=False)
+    assert np.array_equal(a.coords, b.coords) and np.array_equal(a.tris, b.tris) and np.array_equal(a.tags, b.tags)
