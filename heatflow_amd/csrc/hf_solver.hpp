@@ -294,6 +294,7 @@ hipGraphExec_t iteration_graph(hf_ctx* ctx, const LinSys& sys, bool use_amg, int
 // PCG on `sys` started from sys.x.  Jacobi: any system on the pattern; AMG: the main system only.
 // Iteration count / residual are left in h_scal; *pred carries the burst-size hint between calls.
 int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double atol, int max_it, int* pred) {
+  static const bool trace_res = std::getenv("HEATFLOW_TRACE_RES") != nullptr;   // diagnostics: bursts of 2, residual printed after each
   if (!use_amg) {
     // r = b - A x, z = D^-1 r, r.z
     launch_spmv<2>(ctx, sys.A, sys.x, ctx->d_r, ctx->d_part_rz, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn, 0.0,
@@ -318,6 +319,7 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
   }
   // first burst: what the previous solve needed (the counts drift slowly), then check in small bursts
   int burst = std::max(2, std::min(max_it, *pred > 0 ? *pred : (use_amg ? 8 : 32)));
+  if (trace_res) burst = 2;
   // graph unit: 2 multigrid iterations (~40 kernels) or 16 Jacobi iterations (48 kernels) per replay
   const int unit = use_amg ? 2 : 16;
   hipGraphExec_t gexec = (ctx->use_graph && !ctx->prof) ? iteration_graph(ctx, sys, use_amg, unit) : nullptr;
@@ -336,10 +338,12 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
     launched += burst;
     HF_HIP(hipGetLastError());
     HF_TRY(read_scal(ctx));
+    if (trace_res) std::fprintf(stderr, "[res] it %d rel %.3e\n", ctx->h_scal->iters, std::sqrt(ctx->h_scal->zz / std::max(ctx->h_scal->bn2, 1e-300)));
     if (ctx->h_scal->done) break;
     if (launched >= max_it) break;
     burst = std::min(std::max(use_amg ? 2 : 8, launched / 8), max_it - launched);
     burst = std::max(burst, 2);
+    if (trace_res) burst = 2;
   }
   *pred = ctx->h_scal->iters;
   if (ctx->h_scal->done == 2) return fail(ctx, HF_ERR_NOCONV, "PCG breakdown (p.Ap <= 0) after %d iterations", ctx->h_scal->iters);
