@@ -653,3 +653,27 @@ def test_start_vector_kinds_same_answer_fewer_iterations(hip, precond, case_with
             prob2.backend.set_start_vector(3)
     finally:
         prob2.close()
+
+
+@pytest.mark.gpu
+def test_time_kernel_ids_and_state_preservation(hip, case_with_diamond_small):
+    """hf_time_kernel: every live kernel id returns a positive time and leaves the state and the operator
+    alone (HF_K_ASSEMBLE excepted: it asks for a re-assembly); the retired id is refused."""
+    cfg, stack, mesh = case_with_diamond_small
+    prob = make_problem(cfg, stack, mesh, precond=1)
+    try:
+        prob.run(8, time_varying=[prob.bcs[3]])
+        u0 = prob.state()
+        A0 = prob.backend.get_csr()[2].copy()
+        for k in (hip.K_SPMV, hip.K_PCG_SPMV, hip.K_PCG_UPDATE, hip.K_RHS, hip.K_STREAM_READ):
+            assert prob.backend.time_kernel(k, 3) > 0.0
+        assert np.array_equal(prob.state(), u0)
+        assert np.array_equal(prob.backend.get_csr()[2], A0)
+        with pytest.raises(ValueError):
+            prob.backend.time_kernel(hip.K_PCG_DIR, 1)
+        with pytest.raises(ValueError):
+            prob.backend.time_kernel(17, 1)
+        it, _ = prob.step(9 * prob.dt, only=[prob.bcs[3]])          # the loop continues unharmed
+        assert it < 60
+    finally:
+        prob.close()
