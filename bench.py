@@ -124,11 +124,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend, dev_index = "nccl", local_rank
     if world > 1 or os.environ.get("HEATFLOW_BENCH_FORCE_DIST") == "1":   # the latter: rehearse the RCCL path on 1 GPU
         import torch                      # torch first: its bundled HIP runtime must be the one both sides use
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # HEATFLOW_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
+        # (ranks share devices, the mesh travels through host tensors); the measured runs use RCCL
+        backend = os.environ.get("HEATFLOW_BENCH_BACKEND", "nccl")
+        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     def barrier_sync():
         if dist is not None:
@@ -148,7 +156,7 @@ def main():
                 cfg = scale_mesh_sizes(yaml.safe_load(f), args.scale)
             stack = build_stack(cfg)
             mtags = {m.name: k + 1 for k, m in enumerate(stack.materials)}
-        dev = torch.device("cuda", local_rank)
+        dev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
         sizes = torch.tensor([len(coords), len(tris)] if rank == 0 else [0, 0], dtype=torch.int64, device=dev)
         dist.broadcast(sizes, 0)
         n_, ne_ = int(sizes[0]), int(sizes[1])
@@ -162,7 +170,7 @@ def main():
 
     k_sample = None if world == 1 else 3.8 + 0.02 * rank
     precond = 1 if args.precond == "amg" else 0
-    prob = make_problem(cfg, stack, coords, tris, tags, mtags, k_sample, local_rank, precond)
+    prob = make_problem(cfg, stack, coords, tris, tags, mtags, k_sample, dev_index, precond)
     be = prob.backend
     n, nnz = be.n, be.nnz
     for bc in prob.bcs:
@@ -180,7 +188,8 @@ def main():
     gpu_ms = be.last_gpu_ms()
     if dist is not None:
         import torch
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device=torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
 
