@@ -398,7 +398,7 @@ int hf_step(hf_ctx* ctx, const double* g_bc, double rtol, double atol, int32_t m
   if (max_it <= 0 || rtol < 0 || atol < 0) return fail(ctx, HF_ERR_ARG, "hf_step: bad tolerances");
   HF_HIP(hipSetDevice(ctx->dev));
   HF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-  const int rc = step_device(ctx, g_bc, rtol, atol, max_it);
+  const int rc = step_device(ctx, g_bc, nullptr, rtol, atol, max_it);
   if (rc == HF_ERR_HIP) return rc;
   HF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
   HF_HIP(hipStreamSynchronize(ctx->stream));
@@ -419,8 +419,12 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, doubl
   for (int32_t q = 0; q < ns; ++q)
     if (nodes[q] < 0 || nodes[q] >= ctx->n) return fail(ctx, HF_ERR_ARG, "hf_run: node %d outside [0,%d)", nodes[q], ctx->n);
   HF_HIP(hipSetDevice(ctx->dev));
-  DevTemp<double> t_sall;
-  double*& d_sall = t_sall.p;
+  DevTemp<double> t_gall, t_sall;
+  double *&d_gall = t_gall.p, *&d_sall = t_sall.p;
+  if (ctx->nbc > 0) {   // all boundary vectors in one transfer; the steps copy device to device
+    HF_TRY(dev_alloc(ctx, &d_gall, static_cast<size_t>(n_steps) * ctx->nbc));
+    HF_HIP(copy_sync(ctx, d_gall, g_all, sizeof(double) * n_steps * ctx->nbc, hipMemcpyHostToDevice));
+  }
   if (ns > 0) {
     HF_TRY(ensure_samples(ctx, ns));
     HF_TRY(dev_alloc(ctx, &d_sall, static_cast<size_t>(n_steps) * ns));
@@ -429,7 +433,8 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, doubl
   int rc = HF_OK;
   HF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
   for (int32_t s = 0; s < n_steps && rc == HF_OK; ++s) {
-    rc = step_device(ctx, ctx->nbc > 0 ? g_all + static_cast<size_t>(s) * ctx->nbc : nullptr, rtol, atol, max_it);
+    rc = step_device(ctx, ctx->nbc > 0 ? g_all + static_cast<size_t>(s) * ctx->nbc : nullptr,
+                     ctx->nbc > 0 ? d_gall + static_cast<size_t>(s) * ctx->nbc : nullptr, rtol, atol, max_it);
     if (iters) iters[s] = ctx->h_scal->iters;
     if (ns > 0 && rc == HF_OK)
       hipLaunchKernelGGL(k_gather, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, ctx->d_u,

@@ -425,15 +425,17 @@ int prepare_response(hf_ctx* ctx, const double* g_new, int max_it, RespArgs* ra)
   return HF_OK;
 }
 
-// One time step to the boundary values g_host (n_bc doubles on the host).  Leaves iteration count /
-// residual in h_scal.
-int step_device(hf_ctx* ctx, const double* g_host, double rtol, double atol, int max_it) {
+// One time step to the boundary values g_host (n_bc doubles on the host; g_dev = the same values already on
+// the device, or null).  Leaves iteration count / residual in h_scal.
+int step_device(hf_ctx* ctx, const double* g_host, const double* g_dev, double rtol, double atol, int max_it) {
   const int nb = ctx->nbc;
   RespArgs ra{};
   ra.k = 0;
   const bool hist_ok = nb > 0 && ctx->extrapolate && ctx->have_prev && ctx->g_hist >= 2;
   if (ctx->start_kind >= 2 && hist_ok) HF_TRY(prepare_response(ctx, g_host, max_it, &ra));
-  if (nb > 0) HF_HIP(hipMemcpyAsync(ctx->d_g, g_host, sizeof(double) * nb, hipMemcpyHostToDevice, ctx->stream));
+  if (nb > 0)
+    HF_HIP(hipMemcpyAsync(ctx->d_g, g_dev ? g_dev : g_host, sizeof(double) * nb,
+                          g_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   // b = M u^n   (assemble_vector, run_with_diamond.py:476); with a previous step available the same
   // pass writes the extrapolated start vector 2 u^n - u^{n-1}, and the three state buffers rotate
   if (ctx->extrapolate && ctx->have_prev) {
