@@ -318,13 +318,12 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
     if (ctx->h_scal->done == 1) return HF_OK;
   }
   // first burst: what the previous solve needed (the counts drift slowly), then check in small bursts
-  int burst = std::max(2, std::min(max_it, *pred > 0 ? *pred : (use_amg ? 8 : 32)));
+  int burst = std::max(1, std::min(max_it, *pred > 0 ? *pred : (use_amg ? 8 : 32)));
   if (trace_res) burst = 2;
   // graph unit: 2 multigrid iterations (~40 kernels) or 16 Jacobi iterations (48 kernels) per replay
   const int unit = use_amg ? 2 : 16;
   hipGraphExec_t gexec = (ctx->use_graph && !ctx->prof) ? iteration_graph(ctx, sys, use_amg, unit) : nullptr;
   while (true) {
-    burst += burst & 1;  // parity pairs
     ctx->prof_base = launched;
     if (gexec != nullptr) {
       burst = ((burst + unit - 1) / unit) * unit;
@@ -341,8 +340,8 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
     if (trace_res) std::fprintf(stderr, "[res] it %d rel %.3e\n", ctx->h_scal->iters, std::sqrt(ctx->h_scal->zz / std::max(ctx->h_scal->bn2, 1e-300)));
     if (ctx->h_scal->done) break;
     if (launched >= max_it) break;
-    burst = std::min(std::max(use_amg ? 2 : 8, launched / 8), max_it - launched);
-    burst = std::max(burst, 2);
+    // a multigrid iteration that is not needed costs more (11 early-exit launches) than the look that avoids it
+    burst = std::max(1, std::min(std::max(use_amg ? 1 : 8, launched / 8), max_it - launched));
     if (trace_res) burst = 2;
   }
   *pred = ctx->h_scal->iters;
