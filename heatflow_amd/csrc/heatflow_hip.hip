@@ -58,7 +58,7 @@ int hf_destroy(hf_ctx* ctx) {
   (void)hipSetDevice(ctx->dev);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   dev_free(&ctx->d_zr); dev_free(&ctx->d_elem); dev_free(&ctx->d_kappa); dev_free(&ctx->d_rhoc);
-  dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
+  dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_cdict_ptr); dev_free(&ctx->d_cdict); dev_free(&ctx->d_cid); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
   dev_free(&ctx->d_bc_dofs); dev_free(&ctx->d_g); dev_free(&ctx->d_lift_rows); dev_free(&ctx->d_lift_ptr);
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_uprev); dev_free(&ctx->d_ustart);
@@ -104,6 +104,31 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   ctx->max_chunk_nnz_s = 0;
   for (int c = 0; c < ctx->nchunks_s; ++c)
     ctx->max_chunk_nnz_s = std::max(ctx->max_chunk_nnz_s, P.rowptr[std::min<int64_t>(n, (c + 1LL) * TS)] - P.rowptr[c * TS]);
+  // compressed columns per SpMV chunk: sorted unique columns + 16-bit position per nonzero
+  std::vector<int32_t> cdict_ptr(ctx->nchunks_s + 1, 0), cdict;
+  std::vector<uint16_t> cid(P.colidx.size());
+  {
+    std::vector<int32_t> seen(n, -1), lid(n, 0), list;
+    cdict.reserve(static_cast<size_t>(n) + n / 2);
+    ctx->max_cdict = 0;
+    for (int c = 0; c < ctx->nchunks_s; ++c) {
+      const int64_t k0 = P.rowptr[c * TS], k1 = P.rowptr[std::min<int64_t>(n, (c + 1LL) * TS)];
+      list.clear();
+      for (int64_t k = k0; k < k1; ++k) {
+        const int32_t col = P.colidx[k];
+        if (seen[col] != c) { seen[col] = c; list.push_back(col); }
+      }
+      std::sort(list.begin(), list.end());
+      if (list.size() > 65535) return fail(ctx, HF_ERR_ARG, "SpMV chunk %d touches %zu columns (16-bit positions)", c, list.size());
+      for (size_t q = 0; q < list.size(); ++q) lid[list[q]] = static_cast<int32_t>(q);
+      for (int64_t k = k0; k < k1; ++k) cid[k] = static_cast<uint16_t>(lid[P.colidx[k]]);
+      cdict.insert(cdict.end(), list.begin(), list.end());
+      cdict_ptr[c + 1] = static_cast<int32_t>(cdict.size());
+      ctx->max_cdict = std::max(ctx->max_cdict, static_cast<int>(list.size()));
+    }
+  }
+  if (const char* e = std::getenv("HEATFLOW_SPMV_C16")) ctx->c16 = (e[0] != '0');
+  if (static_cast<size_t>(ctx->max_chunk_nnz_s + ctx->max_cdict) * 8 > 64 * 1024) ctx->c16 = false;   // LDS window of the kernel
   ctx->max_blk_nnz = P.max_blk_nnz;
   ctx->ncolors = P.ncolors;
   ctx->elist_len = static_cast<int64_t>(P.blk_elist.size());
@@ -122,6 +147,9 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_TRY(dev_alloc(ctx, &ctx->d_rhoc, ctx->tab_len));
   HF_TRY(dev_alloc(ctx, &ctx->d_rowptr, n + 1));
   HF_TRY(dev_alloc(ctx, &ctx->d_colidx, ctx->nnz));
+  HF_TRY(dev_alloc(ctx, &ctx->d_cdict_ptr, cdict_ptr.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_cdict, cdict.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_cid, cid.size()));
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_eptr, P.blk_eptr.size()));
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_cptr, P.blk_cptr.size()));
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_ent, P.blk_ent.size()));
@@ -145,6 +173,9 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_HIP(copy_sync(ctx, ctx->d_elem, elem.data(), sizeof(int4) * ne, hipMemcpyHostToDevice));
   HF_HIP(copy_sync(ctx, ctx->d_rowptr, P.rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
   HF_HIP(copy_sync(ctx, ctx->d_colidx, P.colidx.data(), sizeof(int32_t) * ctx->nnz, hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_cdict_ptr, cdict_ptr.data(), sizeof(int32_t) * cdict_ptr.size(), hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_cdict, cdict.data(), sizeof(int32_t) * cdict.size(), hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_cid, cid.data(), sizeof(uint16_t) * cid.size(), hipMemcpyHostToDevice));
   HF_HIP(copy_sync(ctx, ctx->d_blk_eptr, P.blk_eptr.data(), sizeof(int32_t) * P.blk_eptr.size(), hipMemcpyHostToDevice));
   HF_HIP(copy_sync(ctx, ctx->d_blk_cptr, P.blk_cptr.data(), sizeof(int32_t) * P.blk_cptr.size(), hipMemcpyHostToDevice));
   HF_HIP(copy_sync(ctx, ctx->d_blk_ent, P.blk_ent.data(), sizeof(int2) * P.blk_ent.size(), hipMemcpyHostToDevice));

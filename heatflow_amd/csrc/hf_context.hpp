@@ -60,6 +60,12 @@ struct hf_ctx {
   int nchunks = 0, P = 0;      // 256-row chunks and grid of the vector kernels / assembly
   int nchunks_s = 0, Ps = 0;   // 512-row chunks and grid of the SpMV kernel (Ps <= P partials)
   int max_chunk_nnz_s = 0;
+  // compressed column indices of the fine operator (ColComp in hf_kernels.hpp): per SpMV chunk a sorted column list,
+  // per nonzero a 16-bit position in it
+  int32_t *d_cdict_ptr = nullptr, *d_cdict = nullptr;
+  uint16_t* d_cid = nullptr;
+  int max_cdict = 0;
+  bool c16 = true;             // HEATFLOW_SPMV_C16=0 keeps the 32-bit column stream
   bool have_mesh = false, have_mat = false, assembled = false;
   double dt = 0.0;
   int mode = 0;

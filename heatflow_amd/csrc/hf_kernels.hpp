@@ -348,7 +348,13 @@ __global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* 
 // The chunk is `rpc` rows (512 for the fine operator; fewer for long-row transfer operators so
 // that a chunk's products fit the 64-KB LDS window).
 // ------------------------------------------------------------------------------------------
-template <int MODE>
+// Compressed column indices of the fine operator (C16): per 512-row chunk the sorted list of the columns it
+// touches (`dict`, ~1.3 entries per row: the chunk's own rows plus a halo) and a 16-bit position in that list
+// per nonzero instead of the 32-bit column.  The chunk's slice of x is staged in LDS once (an almost contiguous
+// gather) and the products look it up there: 10 instead of 12 bytes per nonzero, 5x fewer global gathers.
+struct ColComp { const int32_t* dptr; const int32_t* dict; const uint16_t* id; int xd_off; };
+
+template <int MODE, bool C16 = false>
 __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows per chunk, <= TS */,
                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                               const double* __restrict__ vals, const double* __restrict__ x,
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
                                               const double* __restrict__ dinv, double* __restrict__ pvec,
                                               double* __restrict__ part1, double* __restrict__ part2, double w,
                                               int npart /* partial slots the consumers sum (>= gridDim.x) */,
-                                              int parity) {
+                                              int parity, ColComp comp) {
   extern __shared__ double sprod[];
   __shared__ double s4[TS / 64];
   if ((MODE == 3 || MODE == 4 || MODE == 6 || MODE == 9) && scal->done) return;
@@ -408,21 +414,55 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
       if (MODE == 9 && !first9) e_p = pvec[prow];
       if (MODE == 4 || MODE == 8 || MODE == 9) e_x = x[prow];
     }
-    // products in nnz order: HF_UNROLL predicated value/index loads, then the gathers, in flight per lane
-    for (int k = k0 + threadIdx.x; k < k1; k += HF_UNROLL * TS) {
-      int c[HF_UNROLL];
-      double v[HF_UNROLL], xv[HF_UNROLL];
+    if (C16) {
+      // first batch of values / 16-bit ids is requested before the operand slice is staged, so both latencies overlap
+      double* xd = sprod + comp.xd_off;
+      const int d0 = comp.dptr[chunk], nd = comp.dptr[chunk + 1] - d0;
+      int k = k0 + threadIdx.x;
+      double v[HF_UNROLL];
+      int id[HF_UNROLL];
 #pragma unroll
       for (int u = 0; u < HF_UNROLL; ++u) {
         const bool in = k + u * TS < k1;
-        c[u] = in ? colidx[k + u * TS] : 0;
         v[u] = in ? vals[k + u * TS] : 0.0;
+        id[u] = in ? static_cast<int>(comp.id[k + u * TS]) : 0;
       }
+      for (int i = threadIdx.x; i < nd; i += TS) xd[i] = x[comp.dict[d0 + i]];
+      __syncthreads();
+      while (k < k1) {
+        const int kn = k + HF_UNROLL * TS;
+        double vn[HF_UNROLL];
+        int idn[HF_UNROLL];
 #pragma unroll
-      for (int u = 0; u < HF_UNROLL; ++u) xv[u] = (k + u * TS < k1) ? x[c[u]] : 0.0;
+        for (int u = 0; u < HF_UNROLL; ++u) {
+          const bool in = kn + u * TS < k1;
+          vn[u] = in ? vals[kn + u * TS] : 0.0;
+          idn[u] = in ? static_cast<int>(comp.id[kn + u * TS]) : 0;
+        }
 #pragma unroll
-      for (int u = 0; u < HF_UNROLL; ++u)
-        if (k + u * TS < k1) sprod[k - k0 + u * TS] = v[u] * xv[u];
+        for (int u = 0; u < HF_UNROLL; ++u)
+          if (k + u * TS < k1) sprod[k - k0 + u * TS] = v[u] * xd[id[u]];
+#pragma unroll
+        for (int u = 0; u < HF_UNROLL; ++u) { v[u] = vn[u]; id[u] = idn[u]; }
+        k = kn;
+      }
+    } else {
+      // products in nnz order: HF_UNROLL predicated value/index loads, then the gathers, in flight per lane
+      for (int k = k0 + threadIdx.x; k < k1; k += HF_UNROLL * TS) {
+        int c[HF_UNROLL];
+        double v[HF_UNROLL], xv[HF_UNROLL];
+#pragma unroll
+        for (int u = 0; u < HF_UNROLL; ++u) {
+          const bool in = k + u * TS < k1;
+          c[u] = in ? colidx[k + u * TS] : 0;
+          v[u] = in ? vals[k + u * TS] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < HF_UNROLL; ++u) xv[u] = (k + u * TS < k1) ? x[c[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < HF_UNROLL; ++u)
+          if (k + u * TS < k1) sprod[k - k0 + u * TS] = v[u] * xv[u];
+      }
     }
     __syncthreads();
     if (pin) {

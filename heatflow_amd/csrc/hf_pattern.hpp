@@ -118,7 +118,7 @@ int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const 
   return HF_OK;
 }
 
-size_t spmv_smem_bytes(const hf_ctx* c) { return static_cast<size_t>(c->max_chunk_nnz_s) * 8; }
+size_t spmv_smem_bytes(const hf_ctx* c) { return static_cast<size_t>(c->max_chunk_nnz_s + (c->c16 ? c->max_cdict : 0)) * 8; }
 
 // LDS-staged element kernel into (Mout, Aout) with the given coefficient tables.
 int launch_assemble_lds(hf_ctx* ctx, bool colored, const double* kappa_tab, const double* rhoc_tab, double dt,
@@ -162,16 +162,19 @@ void launch_spmv(hf_ctx* c, const double* vals, const double* x, double* y, doub
                  hipEvent_t ev_stop = nullptr, int parity = 0) {
   // With events: the launch carries them (hipExtLaunchKernelGGL), so they bracket the kernel's own
   // execution on the device - the same interval rocprofv3 reports - not the launch gap before it.
-  if (ev_start != nullptr)
-    hipExtLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), static_cast<std::uint32_t>(spmv_smem_bytes(c)), c->stream,
-                          ev_start, ev_stop, 0u, c->n, c->nchunks_s, static_cast<int>(TS),
-                          static_cast<const int32_t*>(c->d_rowptr), static_cast<const int32_t*>(c->d_colidx), vals, x, y,
-                          c->d_scal, part0, bvec, dinv ? dinv : static_cast<const double*>(c->d_dinv),
-                          pvec, part1, part2, w, c->P, parity);
-  else
-    hipLaunchKernelGGL(k_spmv<MODE>, dim3(c->Ps), dim3(TS), spmv_smem_bytes(c), c->stream, c->n, c->nchunks_s, TS,
-                       c->d_rowptr, c->d_colidx, vals, x, y, c->d_scal, part0, bvec, dinv ? dinv : c->d_dinv, pvec, part1,
-                       part2, w, c->P, parity);
+  const ColComp comp{c->d_cdict_ptr, c->d_cdict, c->d_cid, c->max_chunk_nnz_s};
+#define HF_SPMV_ARGS c->n, c->nchunks_s, static_cast<int>(TS), static_cast<const int32_t*>(c->d_rowptr),                    \
+                     static_cast<const int32_t*>(c->d_colidx), vals, x, y, c->d_scal, part0, bvec,                           \
+                     dinv ? dinv : static_cast<const double*>(c->d_dinv), pvec, part1, part2, w, c->P, parity, comp
+  const std::uint32_t smem = static_cast<std::uint32_t>(spmv_smem_bytes(c));
+  if (c->c16) {
+    if (ev_start != nullptr) hipExtLaunchKernelGGL((k_spmv<MODE, true>), dim3(c->Ps), dim3(TS), smem, c->stream, ev_start, ev_stop, 0u, HF_SPMV_ARGS);
+    else hipLaunchKernelGGL((k_spmv<MODE, true>), dim3(c->Ps), dim3(TS), smem, c->stream, HF_SPMV_ARGS);
+  } else {
+    if (ev_start != nullptr) hipExtLaunchKernelGGL((k_spmv<MODE, false>), dim3(c->Ps), dim3(TS), smem, c->stream, ev_start, ev_stop, 0u, HF_SPMV_ARGS);
+    else hipLaunchKernelGGL((k_spmv<MODE, false>), dim3(c->Ps), dim3(TS), smem, c->stream, HF_SPMV_ARGS);
+  }
+#undef HF_SPMV_ARGS
 }
 
 constexpr int PROF_PAIRS = 64;

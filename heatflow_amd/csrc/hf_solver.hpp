@@ -170,7 +170,7 @@ void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
     hipLaunchKernelGGL(k_spmv<SM>, dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream, m.nrow,
                        m.nchunks, m.rpc, m.ptr, m.idx, m.val, x, y, c->d_scal, static_cast<double*>(nullptr),
                        static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), static_cast<double*>(nullptr),
-                       static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0.0, 0, 0);
+                       static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0.0, 0, 0, ColComp{nullptr, nullptr, nullptr, 0});
     return;
   }
   if (m.lanes > 64) {  // very long rows: a workgroup per row
