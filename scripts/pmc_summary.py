@@ -12,7 +12,10 @@ fetch_dir, write_dir, out, n, ne, nnz = sys.argv[1], sys.argv[2], sys.argv[3], i
 
 def short(name):
     m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else name[:30]
+    if not m:
+        return name[:30]
+    targs = re.sub(r",\s*(true|false)", "", m.group(2) or "")     # k_spmv<9, true> (compressed columns) -> k_spmv<9>
+    return m.group(1) + targs
 
 
 res = {}
@@ -22,7 +25,7 @@ for kind, d in (("fetch", fetch_dir), ("write", write_dir)):
     for r in csv.DictReader(open(f)):
         acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     res[kind] = acc
-alg = {"k_spmv<9>": 12 * nnz + 44 * n, "k_spmv<1>": 12 * nnz + 20 * n, "k_spmv<0>": 12 * nnz + 20 * n, "k_spmv<3>": 12 * nnz + 28 * n,
+alg = {"k_spmv<9>": 12 * nnz + 44 * n, "k_spmv<0>": 12 * nnz + 20 * n, "k_spmv<3>": 12 * nnz + 28 * n,
        "k_spmv<4>": 12 * nnz + 36 * n, "k_pcg_update_amg": 64 * n, "k_pcg_update": 64 * n, "k_spmv<8>": 12 * nnz + 36 * n, "k_assemble_lds<false>": 16 * ne + 16 * n + 16 * nnz}
 kern = {}
 with open(out + ".csv", "w") as f:
