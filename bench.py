@@ -263,7 +263,7 @@ def main():
                        "points": "1 sweep point per GPU (kappa_sample = 3.8 + 0.02*rank)" if world > 1 else "1 run",
                        "gpu_ms_per_step_events": gpu_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<9> (PCG iteration head: CSR SpMV with the direction update p, Ap fused)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<9> (PCG iteration head: CSR SpMV with the direction update p, Ap fused; the column stream is 16-bit compressed, so the measured traffic is below the formula bytes)",
                          "bytes_per_launch": spmv_bytes, "us_per_launch": spmv_us,
                          "us_per_launch_in_loop_events": spmv_us_loop, "us_back_to_back": k_us,
                          "measured_stream_read": {"GB/s": stream_gbs, "us": read_us, "bytes": 12 * nnz,
