@@ -1,5 +1,5 @@
 """Multigrid-PCG vs Jacobi-PCG over a spread of operators (mesh scale, kappa_sample, dt): iterations,
-agreement of the fields after 8 steps, fallback count."""
+agreement of the fields after 8 steps from the onset of the heating, fallback count."""
 import os, sys, copy, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,7 +20,8 @@ for name, scale in (("geballe_with_diamond", 1.0), ("geballe_with_diamond", 3.0)
             prob = make_problem(cfg, stack, mesh, precond=pc, max_it=50000)
             for bc in prob.bcs: bc.update(0.0)
             try:
-                for k in range(8): prob.step((k + 1) * prob.dt)
+                k0 = int(3.6e-7 / prob.dt)           # start where the heating curve starts (short steps would see a constant field)
+                for k in range(k0, k0 + 8): prob.step((k + 1) * prob.dt)
                 out[pc] = (prob.state(), max(prob.iters), prob.backend.amg_info()["jacobi_fallbacks"] if pc else 0)
             except Exception as e:
                 out[pc] = (None, str(e)[:80], -1)
