@@ -364,27 +364,65 @@ int hf_flux_setup(hf_ctx* ctx) {
   return HF_OK;
 }
 
-int hf_flux_project(hf_ctx* ctx, double rtol, int32_t max_it, double* grad_z, double* grad_r, int32_t* iters) {
+int hf_flux_solve(hf_ctx* ctx, int32_t components, double rtol, int32_t max_it, int32_t* iters) {
   if (!ctx) return HF_ERR_ARG;
-  if (!ctx->flux_ready) return fail(ctx, HF_ERR_STATE, "hf_flux_project before hf_flux_setup");
-  if (max_it <= 0 || rtol < 0) return fail(ctx, HF_ERR_ARG, "hf_flux_project: bad tolerances");
+  if (!ctx->flux_ready) return fail(ctx, HF_ERR_STATE, "hf_flux_solve before hf_flux_setup");
+  if (max_it <= 0 || rtol < 0 || components < 0 || components > 3) return fail(ctx, HF_ERR_ARG, "hf_flux_solve: bad arguments");
   HF_HIP(hipSetDevice(ctx->dev));
-  const int n = ctx->n;
-  hipLaunchKernelGGL(k_grad_rhs, dim3(ctx->nblk_a), dim3(RBA), 0, ctx->stream, n, ctx->d_blk_eptr, ctx->d_blk_ent,
+  hipLaunchKernelGGL(k_grad_rhs, dim3(ctx->nblk_a), dim3(RBA), 0, ctx->stream, ctx->n, ctx->d_blk_eptr, ctx->d_blk_ent,
                      ctx->d_zr, ctx->d_u, ctx->d_bz, ctx->d_br);
   HF_HIP(hipGetLastError());
-  // two scalar mass-matrix solves, each warm-started from the previous projection
-  const LinSys sz{ctx->d_M1, ctx->d_dinv1, ctx->d_gz, ctx->d_bz};
-  int rc = pcg_solve(ctx, sz, false, rtol, 0.0, max_it, &ctx->pred_flux[0]);
-  if (iters) iters[0] = ctx->h_scal->iters;
+  if (iters) iters[0] = iters[1] = 0;
+  ctx->flux_valid = 0;
+  // one scalar mass-matrix solve per wanted component, each warm-started from its previous projection
+  if (components & 1) {
+    const LinSys sz{ctx->d_M1, ctx->d_dinv1, ctx->d_gz, ctx->d_bz};
+    const int rc = pcg_solve(ctx, sz, false, rtol, 0.0, max_it, &ctx->pred_flux[0]);
+    if (iters) iters[0] = ctx->h_scal->iters;
+    if (rc != HF_OK) return rc;
+    ctx->flux_valid |= 1;
+  }
+  if (components & 2) {
+    const LinSys sr{ctx->d_M1, ctx->d_dinv1, ctx->d_gr, ctx->d_br};
+    const int rc = pcg_solve(ctx, sr, false, rtol, 0.0, max_it, &ctx->pred_flux[1]);
+    if (iters) iters[1] = ctx->h_scal->iters;
+    if (rc != HF_OK) return rc;
+    ctx->flux_valid |= 2;
+  }
+  return HF_OK;
+}
+
+int hf_flux_project(hf_ctx* ctx, double rtol, int32_t max_it, double* grad_z, double* grad_r, int32_t* iters) {
+  if (!ctx) return HF_ERR_ARG;
+  const int rc = hf_flux_solve(ctx, (grad_z ? 1 : 0) | (grad_r ? 2 : 0), rtol, max_it, iters);
   if (rc != HF_OK) return rc;
-  const LinSys sr{ctx->d_M1, ctx->d_dinv1, ctx->d_gr, ctx->d_br};
-  rc = pcg_solve(ctx, sr, false, rtol, 0.0, max_it, &ctx->pred_flux[1]);
-  if (iters) iters[1] = ctx->h_scal->iters;
-  if (rc != HF_OK) return rc;
+  const int n = ctx->n;
   if (grad_z) HF_HIP(hipMemcpyAsync(grad_z, ctx->d_gz, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   if (grad_r) HF_HIP(hipMemcpyAsync(grad_r, ctx->d_gr, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   HF_HIP(hipStreamSynchronize(ctx->stream));
+  return HF_OK;
+}
+
+int hf_flux_sample(hf_ctx* ctx, int32_t ns, const int32_t* nodes, double* grad_z, double* grad_r) {
+  if (!ctx) return HF_ERR_ARG;
+  if (!ctx->flux_ready) return fail(ctx, HF_ERR_STATE, "hf_flux_sample before hf_flux_setup");
+  if (ns < 0 || (ns > 0 && !nodes)) return fail(ctx, HF_ERR_ARG, "hf_flux_sample: bad arguments");
+  if ((grad_z && !(ctx->flux_valid & 1)) || (grad_r && !(ctx->flux_valid & 2)))
+    return fail(ctx, HF_ERR_STATE, "hf_flux_sample: that component was not solved by the last hf_flux_solve / hf_flux_project");
+  for (int32_t q = 0; q < ns; ++q)
+    if (nodes[q] < 0 || nodes[q] >= ctx->n) return fail(ctx, HF_ERR_ARG, "hf_flux_sample: node %d outside [0,%d)", nodes[q], ctx->n);
+  if (ns == 0) return HF_OK;
+  HF_HIP(hipSetDevice(ctx->dev));
+  HF_TRY(ensure_samples(ctx, ns));
+  HF_HIP(hipMemcpyAsync(ctx->d_samp_idx, nodes, sizeof(int32_t) * ns, hipMemcpyHostToDevice, ctx->stream));
+  for (int comp = 0; comp < 2; ++comp) {
+    double* out = comp ? grad_r : grad_z;
+    if (!out) continue;
+    hipLaunchKernelGGL(k_gather, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx,
+                       comp ? ctx->d_gr : ctx->d_gz, ctx->d_samp);
+    HF_HIP(hipMemcpyAsync(out, ctx->d_samp, sizeof(double) * ns, hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+  }
   return HF_OK;
 }
 

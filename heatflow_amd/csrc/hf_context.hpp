@@ -143,6 +143,7 @@ struct hf_ctx {
   double *d_z = nullptr, *d_z2 = nullptr;
   // read-flux projection (hf_flux_setup): unit-rho_c r-weighted mass matrix and the projected gradient
   bool flux_ready = false;
+  int flux_valid = 0;          // components (bit 0 z, bit 1 r) the last projection solved
   double *d_M1 = nullptr, *d_dinv1 = nullptr, *d_gz = nullptr, *d_gr = nullptr, *d_bz = nullptr, *d_br = nullptr;
   int pred_flux[2] = {0, 0};
   // hipGraph replay of the PCG loops: one executable graph per (system, preconditioner), each holding

@@ -229,8 +229,8 @@ class SimulationSession:
                 t = (step + 1) * dt
                 it, _ = prob.step(t, only=varying)
                 if flux is not None:
-                    _, grad_r = prob.backend.flux_project(self.rtol, 5000, want_z=False)
-                    flux.record(t, grad_r)
+                    prob.backend.flux_solve(self.rtol, 5000, want_z=False)          # d/dr only, on the device
+                    flux.record_sampled(t, prob.backend.flux_sample(flux.nodes, want_z=False)[1])
                 if field_sink is not None:
                     u = prob.state()
                     field_sink(t, u)
@@ -278,11 +278,20 @@ class FluxSampler:
         self.axis_nodes = axis[order]
         self.axis_z = z[self.axis_nodes]
         self.times, self.rows, self.raw_rows = [], [], []
+        # the only nodes whose gradient is ever read: band groups first, axis nodes last (hf_flux_sample order)
+        self.nodes = np.concatenate(self.groups + [self.axis_nodes]).astype(np.int32) if self.groups else self.axis_nodes.astype(np.int32)
+        self._cuts = np.cumsum([len(g) for g in self.groups])
 
     def record(self, t, grad_r):
+        """grad_r: the full nodal field."""
+        self.record_sampled(t, np.asarray(grad_r)[self.nodes])
+
+    def record_sampled(self, t, values):
+        """values: d T/d r at ``self.nodes`` (what hf_flux_sample returns)."""
         self.times.append(float(t))
-        self.rows.append([float(np.mean(grad_r[g])) for g in self.groups])
-        self.raw_rows.append(grad_r[self.axis_nodes].astype(float).tolist())
+        parts = np.split(values, self._cuts) if len(self._cuts) else [values]
+        self.rows.append([float(np.mean(p)) for p in parts[:len(self.groups)]])
+        self.raw_rows.append(parts[-1].astype(float).tolist())
 
     @staticmethod
     def _write(path, times, columns, rows):

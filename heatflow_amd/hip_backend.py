@@ -22,7 +22,7 @@ K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS, K_STREAM_READ = 
 EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_materials",
     "hf_update_kappa", "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_set_start_vector", "hf_get_response_solves", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
-    "hf_flux_setup", "hf_flux_project", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
+    "hf_flux_setup", "hf_flux_project", "hf_flux_solve", "hf_flux_sample", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
 
 
@@ -98,6 +98,8 @@ def load_library():
         "hf_run": [vp, i32, pd, dbl, dbl, i32, i32, pi, pd, pi],
         "hf_flux_setup": [vp],
         "hf_flux_project": [vp, dbl, i32, pd, pd, pi],
+        "hf_flux_solve": [vp, i32, dbl, i32, pi],
+        "hf_flux_sample": [vp, i32, pi, pd, pd],
         "hf_get_sizes": [vp, pi, pi, C.POINTER(i64), pi],
         "hf_get_csr": [vp, pi, pi, pd, pd],
         "hf_spmv": [vp, i32, pd, pd],
@@ -283,6 +285,21 @@ class HeatflowHIP:
         it = np.zeros(2, dtype=np.int32)
         self._check(self._lib.hf_flux_project(self._ctx, rtol, int(max_it), _pd(gz), _pd(gr), _pi(it)))
         self.last_flux_iters = it
+        return gz, gr
+
+    def flux_solve(self, rtol=1e-10, max_it=5000, want_z=True, want_r=True):
+        """Project the current state's gradient on the device only (no copy); returns the iteration counts."""
+        it = np.zeros(2, dtype=np.int32)
+        self._check(self._lib.hf_flux_solve(self._ctx, (1 if want_z else 0) | (2 if want_r else 0), rtol, int(max_it), _pi(it)))
+        self.last_flux_iters = it
+        return it
+
+    def flux_sample(self, nodes, want_z=True, want_r=True):
+        """(grad_z[nodes], grad_r[nodes]) of the last projection."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        gz = np.empty(len(nodes), dtype=np.float64) if want_z else None
+        gr = np.empty(len(nodes), dtype=np.float64) if want_r else None
+        self._check(self._lib.hf_flux_sample(self._ctx, len(nodes), _pi(nodes), _pd(gz), _pd(gr)))
         return gz, gr
 
     # -- inspection ----------------------------------------------------------------------

@@ -145,11 +145,17 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_bc_all, double rtol, do
 /* Read-flux projection of run_no_diamond (reference run_no_diamond.py:471-491 set-up, :543-550 per
  * step): grad_smooth = L2 projection of grad(T) onto vector P1 with weight r.  hf_flux_setup
  * assembles the unit-coefficient r-weighted mass matrix on the mesh's pattern (once per mesh);
- * hf_flux_project projects the CURRENT state: two Jacobi-PCG solves (z and r component, same
- * stopping rule as hf_step), results copied to grad_z / grad_r (n values each, either may be
- * NULL); iters = 2 entries (may be NULL). */
+ * hf_flux_project projects the CURRENT state: one Jacobi-PCG solve per component (z, r; the 2n x 2n
+ * system of the reference is block diagonal, so the components decouple exactly; same stopping rule as
+ * hf_step), results copied to grad_z / grad_r (n values each).  A NULL output skips that component's
+ * solve altogether (run_no_diamond's outputs only use d/dr, :553-566).  iters = 2 entries (may be NULL).
+ * hf_flux_solve does the same without any copy (components: bit 0 = z, bit 1 = r); hf_flux_sample then
+ * reads the projected gradient at n_s nodes (either output may be NULL) - what the band / axis averages
+ * of run_no_diamond.py:494-513, 553-566 need, instead of two n-vectors per step. */
 int hf_flux_setup(hf_ctx* ctx);
 int hf_flux_project(hf_ctx* ctx, double rtol, int32_t max_it, double* grad_z, double* grad_r, int32_t* iters);
+int hf_flux_solve(hf_ctx* ctx, int32_t components, double rtol, int32_t max_it, int32_t* iters);
+int hf_flux_sample(hf_ctx* ctx, int32_t n_s, const int32_t* nodes, double* grad_z, double* grad_r);
 
 int hf_get_sizes(hf_ctx* ctx, int32_t* n, int32_t* n_e, int64_t* nnz, int32_t* n_bc);
 /* Any pointer may be NULL.  A is the matrix as it stands (eliminated when BCs are set). */

@@ -677,3 +677,32 @@ def test_time_kernel_ids_and_state_preservation(hip, case_with_diamond_small):
         assert it < 60
     finally:
         prob.close()
+
+
+@pytest.mark.gpu
+def test_flux_solve_and_sample_match_the_full_projection(hip, case_no_diamond_small):
+    """hf_flux_solve + hf_flux_sample (what the driver uses: d/dr at the band and axis nodes only) against
+    hf_flux_project's full vectors; a component that was not solved cannot be sampled."""
+    cfg, stack, mesh = case_no_diamond_small
+    prob = make_problem(cfg, stack, mesh, precond=1)
+    try:
+        prob.run(12, time_varying=[prob.bcs[3]])
+        be = prob.backend
+        be.flux_setup()
+        gz, gr = be.flux_project(1e-12, 5000)
+        nodes = np.random.default_rng(3).integers(0, prob.n, size=257).astype(np.int32)
+        it = be.flux_solve(1e-12, 5000, want_z=False)
+        assert it[0] == 0 and it[1] >= 0
+        _, sr = be.flux_sample(nodes, want_z=False)
+        assert np.abs(sr - gr[nodes]).max() <= 1e-9 * np.abs(gr).max()
+        with pytest.raises(hip.HipError):
+            be.flux_sample(nodes, want_z=True, want_r=False)       # z was skipped by the last solve
+        be.flux_solve(1e-12, 5000)
+        sz, sr = be.flux_sample(nodes)
+        assert np.abs(sz - gz[nodes]).max() <= 1e-9 * np.abs(gz).max()
+        assert np.abs(sr - gr[nodes]).max() <= 1e-9 * np.abs(gr).max()
+        with pytest.raises(ValueError):
+            be.flux_sample(np.array([prob.n], dtype=np.int32))
+        assert be.flux_sample(np.zeros(0, dtype=np.int32)) [0].shape == (0,)
+    finally:
+        prob.close()
