@@ -143,6 +143,30 @@ def test_c3_one_million_dof_first_steps_match_oracle(hip, c3):
         prob.close()
 
 
+def test_c3_one_million_dof_whole_run_watchers_and_final_field_match_oracle(hip, c3):
+    """The whole headline run (all 100 steps of BASELINE C3 through hf_run, as bench.py drives it) against the
+    oracle: the two watcher curves at every step and the final field.  Error does not accumulate: every step
+    is solved to the same tolerance and the loop is a contraction."""
+    from heatflow_amd.geometry import watcher_points
+    from heatflow_amd.solver import nearest_nodes
+
+    cfg, stack, mesh = c3
+    nsteps = int(cfg["timing"]["num_steps"])
+    assert nsteps == 100
+    wp = watcher_points(cfg)
+    nodes = nearest_nodes(mesh.coords, [wp["pside"], wp["oside"]])
+    ref = oracle_run(cfg, mesh, nsteps, keep_fields=False, watcher_nodes=nodes)
+    prob = make_problem(cfg, stack, mesh, precond=1)
+    try:
+        _, samples, iters = prob.run(nsteps, watcher_nodes=nodes, time_varying=[prob.bcs[3]])
+        assert np.abs(samples - ref["watchers"]).max() <= 1e-4
+        assert np.abs(prob.state() - ref["solver"].u).max() <= 1e-4
+        assert ref["watchers"][:, 0].max() - 300.0 > 100.0          # the p-side coupler really heats up
+        assert prob.backend.response_solves() == 1 and max(iters) < 40
+    finally:
+        prob.close()
+
+
 def test_c4_stock_read_flux_matches_oracle(hip, c2):
     """BASELINE config 4 (geballe_no_diamond_read_flux.yaml: the C2 mesh, 50 steps, gradient
     projection every step): projected dT/dr on the axis against the oracle's projection."""
