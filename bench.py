@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scale", type=float, default=MESH_SCALE, help="factor on every mats.*.mesh (0.43 -> ~1.04M DOF)")
-    ap.add_argument("--cpu-steps", type=int, default=20, help="steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=60, help="steps of the CPU baseline sample (0 = skip): with the LU factorisation ~10-15 s of host work")
     ap.add_argument("--profile-steps", type=int, default=4, help="extra steps with in-situ SpMV event timing")
     ap.add_argument("--precond", choices=["amg", "jacobi"], default="amg",
                     help="PCG preconditioner of the timed run: smoothed-aggregation V-cycle (default) or plain Jacobi")
