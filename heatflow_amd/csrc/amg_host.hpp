@@ -42,7 +42,9 @@ inline Csr transpose(const Csr& A) {
   return T;
 }
 
-// C = A * B (Gustavson, dense accumulator), columns of every row sorted.
+// C = A * B (Gustavson, dense accumulator), columns of every row sorted.  Serial on purpose: row ranges on host
+// threads were measured slower than one thread on the GPU boxes (0.05 s serial, 0.11-0.29 s with 2-16 threads for
+// the 1M-row A*P; scripts/micro notes) - their cores are a share of a large NUMA machine.
 inline Csr spgemm(const Csr& A, const Csr& B) {
   Csr C;
   C.nrow = A.nrow;
@@ -180,13 +182,29 @@ struct Level {
   double omega = 0.0;       // Jacobi damping 4 / (3 rho)
 };
 
-// S = I - w D^-1 A (same pattern as A; A carries its diagonal)
-inline Csr jacobi_iteration_matrix(const Csr& A, const std::vector<double>& dinv, double w) {
-  Csr S = A;
-  for (int i = 0; i < A.nrow; ++i)
-    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k)
-      S.val[k] = (A.idx[k] == i ? 1.0 : 0.0) - w * dinv[i] * A.val[k];
-  return S;
+// Pt = (I - w D^-1 A) P = P - w D^-1 (A P), from the product A P the Galerkin step has anyway: per row a merge of two
+// sorted column lists (rows of P without an aggregate stay empty in P; their A P part is kept: they are smoothed
+// against their neighbours' corrections like every other row)
+inline Csr smoothed_by_product(const Csr& P, const Csr& AP, const std::vector<double>& dinv, double w) {
+  Csr C;
+  C.nrow = P.nrow;
+  C.ncol = P.ncol;
+  C.ptr.assign(static_cast<size_t>(P.nrow) + 1, 0);
+  C.idx.reserve(AP.idx.size());
+  C.val.reserve(AP.idx.size());
+  for (int i = 0; i < P.nrow; ++i) {
+    int a = P.ptr[i], b = AP.ptr[i];
+    const int a1 = P.ptr[i + 1], b1 = AP.ptr[i + 1];
+    const double s = -w * dinv[i];
+    while (a < a1 || b < b1) {
+      const int ca = a < a1 ? P.idx[a] : INT32_MAX, cb = b < b1 ? AP.idx[b] : INT32_MAX;
+      if (ca == cb) { C.idx.push_back(ca); C.val.push_back(P.val[a] + s * AP.val[b]); ++a; ++b; }
+      else if (ca < cb) { C.idx.push_back(ca); C.val.push_back(P.val[a]); ++a; }
+      else { C.idx.push_back(cb); C.val.push_back(s * AP.val[b]); ++b; }
+    }
+    C.ptr[i + 1] = static_cast<int>(C.idx.size());
+  }
+  return C;
 }
 
 // [G | Pt] with G = 2 w D^-1 - w^2 D^-1 A D^-1 (pattern of A) and the columns of Pt shifted by A.ncol
@@ -258,7 +276,7 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
       Csr AP = spgemm(A, L.P);
       Csr Ac = spgemm(L.R, AP);
       if (lev > 0) {                                 // intermediate level: fused legs of the cycle
-        const Csr Pt = spgemm(jacobi_iteration_matrix(A, L.dinv, L.omega), L.P);
+        const Csr Pt = smoothed_by_product(L.P, AP, L.dinv, L.omega);
         L.Rt = transpose(Pt);
         L.GP = fused_up_leg(A, L.dinv, L.omega, Pt);
       }
