@@ -120,6 +120,9 @@ __global__ __launch_bounds__(RBA) void k_assemble_lds(int n, int cap, const int3
                                                       const double* __restrict__ rhoc_tab, double dt,
                                                       double* __restrict__ Mv, double* __restrict__ Av) {
   extern __shared__ double smem[];
+  // slab layout: the coloured variant keeps (M, A) of a slot side by side (one 16-byte read-modify-write per entry:
+  // 80 -> 74 us at C3); the atomic variant keeps two arrays (atomics on neighbouring words collide: 50 vs 56 us)
+  double2* sMA = reinterpret_cast<double2*>(smem);
   double* sM = smem;
   double* sA = smem + cap;
   int* sR = reinterpret_cast<int*>(smem + 2 * cap);
@@ -130,8 +133,12 @@ __global__ __launch_bounds__(RBA) void k_assemble_lds(int n, int cap, const int3
   const int k0 = rowptr[r0];
   const int nk = rowptr[r1] - k0;
   for (int k = threadIdx.x; k < nk; k += RBA) {
-    sM[k] = 0.0;
-    sA[k] = 0.0;
+    if (COLORED) {
+      sMA[k] = make_double2(0.0, 0.0);
+    } else {
+      sM[k] = 0.0;
+      sA[k] = 0.0;
+    }
   }
   for (int k = threadIdx.x; k <= r1 - r0; k += RBA) sR[k] = rowptr[r0 + k] - k0;
   __syncthreads();
@@ -154,8 +161,10 @@ __global__ __launch_bounds__(RBA) void k_assemble_lds(int n, int cap, const int3
         const int slot = base + static_cast<int>(off);
         const int q = sym_index(a, b);
         if (COLORED) {
-          sM[slot] += m[q];
-          sA[slot] += av6[q];
+          double2 t = sMA[slot];
+          t.x += m[q];
+          t.y += av6[q];
+          sMA[slot] = t;
         } else {
           atomicAdd(&sM[slot], m[q]);
           atomicAdd(&sA[slot], av6[q]);
@@ -193,8 +202,14 @@ __global__ __launch_bounds__(RBA) void k_assemble_lds(int n, int cap, const int3
   }
   __syncthreads();
   for (int k = threadIdx.x; k < nk; k += RBA) {
-    Mv[k0 + k] = sM[k];
-    Av[k0 + k] = sA[k];
+    if (COLORED) {
+      const double2 t = sMA[k];
+      Mv[k0 + k] = t.x;
+      Av[k0 + k] = t.y;
+    } else {
+      Mv[k0 + k] = sM[k];
+      Av[k0 + k] = sA[k];
+    }
   }
 }
 
