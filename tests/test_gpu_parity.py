@@ -6,9 +6,11 @@ Tolerances (float64):
   * temperature field, every time step     |T_hip - T_oracle| <= 1e-4 K  (fields are 300..2700 K,
     i.e. ~4e-8 relative; measured ~3e-6 K at the default PCG rtol = 1e-10)
 """
+import os
 import numpy as np
 import pytest
 
+from conftest import ROOT
 from helpers import csr_values_on_pattern, make_problem, material_tables, oracle_run, reference_bcs
 
 pytestmark = pytest.mark.gpu
@@ -706,3 +708,35 @@ def test_flux_solve_and_sample_match_the_full_projection(hip, case_no_diamond_sm
         assert be.flux_sample(np.zeros(0, dtype=np.int32)) [0].shape == (0,)
     finally:
         prob.close()
+
+
+@pytest.mark.gpu
+def test_compressed_and_plain_column_streams_give_identical_results(hip, tmp_path):
+    """The 16-bit column positions (default) and the 32-bit column stream (HEATFLOW_SPMV_C16=0) form the same
+    products in the same order: SpMV and a short time loop agree bit for bit.  One subprocess per setting, since
+    the switch is read when the mesh is set."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(os.path.join(ROOT, 'tests'))!r})\n"
+        "from conftest import build_case\n"
+        "from helpers import make_problem\n"
+        "cfg, stack, mesh = build_case('geballe_with_diamond', 4.0)\n"
+        "prob = make_problem(cfg, stack, mesh, precond=1)\n"
+        "x = np.random.default_rng(1).standard_normal(prob.n)\n"
+        "y = prob.backend.spmv(x, 0)\n"
+        "prob.run(10, time_varying=[prob.bcs[3]])\n"
+        "np.savez(sys.argv[1], y=y, u=prob.state(), iters=np.array(prob.iters))\n"
+        "prob.close()\n")
+    out = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, HEATFLOW_SPMV_C16=flag)
+        res = subprocess.run([sys.executable, str(script), str(tmp_path / f"o{flag}.npz")], env=env, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out[flag] = np.load(tmp_path / f"o{flag}.npz")
+    assert np.array_equal(out["1"]["y"], out["0"]["y"])
+    assert np.array_equal(out["1"]["u"], out["0"]["u"])
+    assert np.array_equal(out["1"]["iters"], out["0"]["iters"])
