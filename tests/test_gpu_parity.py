@@ -740,3 +740,32 @@ def test_compressed_and_plain_column_streams_give_identical_results(hip, tmp_pat
     assert np.array_equal(out["1"]["y"], out["0"]["y"])
     assert np.array_equal(out["1"]["u"], out["0"]["u"])
     assert np.array_equal(out["1"]["iters"], out["0"]["iters"])
+
+
+def test_two_heated_lines_take_two_response_directions(hip, case_no_diamond_small):
+    """Two independently driven Dirichlet lines (the two-sided extension): the second difference of the boundary
+    vector spans two directions, the library learns exactly two responses and still reproduces the kind-0 answer."""
+    from conftest import HEATING_CSV
+    from heatflow_amd.bc import P1Space, RowDirichletBC
+    from heatflow_amd.heating import HeatingCurve
+    from heatflow_amd.solver import HeatProblem
+
+    cfg, stack, mesh = case_no_diamond_small
+    bcs, ic, _ = reference_bcs(cfg, stack, mesh)
+    heat_o = HeatingCurve(HEATING_CSV, ic, float(cfg["heating"]["fwhm"]), column="oside")
+    bcs.append(RowDirichletBC(P1Space(mesh.coords), "x", coord=stack.heated_z_oside, length=abs(stack.r_sample) * 2,
+                              center=0.0, value=heat_o.gaussian))
+    tag_to_k, tag_to_rc = material_tables(stack, mesh)
+    dt = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
+    out = {}
+    for kind in (0, 2):
+        prob = HeatProblem(mesh.coords, mesh.tris, mesh.tags, tag_to_k, tag_to_rc, dt, bcs, ic, precond=1)
+        try:
+            prob.backend.set_start_vector(kind)
+            _, _, iters = prob.run(30, time_varying=bcs[3:])
+            out[kind] = (prob.state(), int(np.sum(iters)), prob.backend.response_solves())
+        finally:
+            prob.close()
+    assert out[0][2] == 0 and out[2][2] == 2
+    assert np.abs(out[2][0] - out[0][0]).max() <= 2e-5
+    assert out[2][1] < out[0][1]
