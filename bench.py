@@ -2,22 +2,34 @@
 """Headline benchmark: DOF-updates/s of the backward-Euler time loop on geballe_with_diamond
 refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c3|sweep64]
 
-* A "step" is one time step of the hot path: b = M u^n, lifting, set_bc, Jacobi-PCG solve
-  (run_with_diamond.py:469-481), all inputs resident in HBM.  The W warm-up steps are the
-  first W steps of the simulation (steps 0-3 carry no heating yet and converge in zero
-  iterations), the K timed steps follow them.
-* N > 1 (launched by torch.distributed.run, one rank per GPU): every rank solves its own
-  sweep point (kappa_sample = 3.8 + 0.02*rank, the sweep_test.py grid) on the same mesh,
-  which rank 0 builds and broadcasts over RCCL; no data-path collective.  value = all ranks'
-  DOF-updates / max-over-ranks time ("weak" scaling).
+* ``--gpus N`` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself
+  (``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a fresh child, before torch or HIP
+  is touched here) and forwards the child's single JSON line.  Under an outside launcher (the driver's
+  ``torch.distributed.run``) WORLD_SIZE is set and the ranks run directly.  ``n_gpus`` in the JSON is the
+  world size the process group actually has.
+* workload ``c3`` (default, the configuration the metric is quoted on): a "step" is one time step of the hot
+  path: b = M u^n, lifting, set_bc, PCG solve (run_with_diamond.py:469-481), all inputs resident in HBM.  The W
+  warm-up steps are the first W steps of the simulation (steps 0-3 carry no heating yet and converge in zero
+  iterations), the K timed steps follow them.  N > 1: every rank solves its own sweep point
+  (kappa_sample = 3.8 + 0.02*rank, the sweep_test.py grid) on the same mesh, which rank 0 builds and
+  broadcasts over RCCL together with its tag map; no data-path collective.  value = all ranks' DOF-updates /
+  max-over-ranks time ("weak" scaling).
+* workload ``sweep64`` (BASELINE C5): 64 kappa_sample values (parameter_sweep.get_k_values(count=64)) at stock
+  mesh size, point i -> rank i mod world, 4 points in flight per rank; K = time steps per point (default: the
+  config's 100), W = untimed steps every solver session runs first.  value = 64*n*K / wall of the point loop
+  (max over ranks), "strong" scaling (the 64 points are fixed).  The same sweep is also run as a side
+  measurement of the default workload (``config.sweep64``; ``--sweep-points 0`` skips it).
 * roofline: the dominant kernel is the PCG iteration head k_spmv<9> (CSR SpMV A z with the direction
   update p <- z + beta p, Ap <- A z + beta Ap fused).  achieved = algorithmic bytes per launch
   (SpMV 12*nnz + 20*n of SURVEY.md section 8d, plus 24*n for reading the old p and Ap and writing p)
-  / its average duration over 100 launches on the live matrix, HIP events on the solver's stream,
-  right after the timed region (agrees with rocprofv3's in-loop average for the kernel); the in-loop
-  kernel-attached event timing, which also contains the gap to the previous kernel, is reported too.
+  / its average duration INSIDE the loop (kernel-attached HIP events on the solver's stream on the launches
+  of extra steps right after the timed region; agrees with rocprofv3's in-loop figure, profiles/).  The
+  back-to-back figure (100 launches) and the bytes the compressed column format really moves are beside it.
+  At 1M DOF the iteration's working set sits in the 256 MiB Infinity Cache; ``roofline.hbm_resident`` repeats
+  the measurement on a mesh whose matrix is far beyond it (``--hbm-scale``, 16M DOF).  ``roofline.assembly``
+  holds the element kernel's variants.
 * cpu_baseline: the oracle (reference algorithm: assemble once, sparse LU once, two
   triangular solves per step; SciPy SuperLU, 1 thread) on the same mesh, rank 0, N = 1 only.
 """
@@ -29,11 +41,9 @@ for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS", "NUMEXP
 
 import argparse
 import json
+import subprocess
 import sys
 import time
-
-import numpy as np
-import yaml
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -41,9 +51,62 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 TARGET_DOF = 1.0e6
 MESH_SCALE = 0.43          # all `mesh:` values x 0.43 -> 1.04 M nodes (within +-5 % of 1.0e6)
+HBM_SCALE = 0.1075         # -> 16 M nodes: matrix 1.3 GB, vectors 128 MB each, nothing stays in the 256 MiB Infinity Cache
+SWEEP_POINTS = 64          # BASELINE C5
+SWEEP_CONCURRENT = 4       # points in flight per rank (stock-size kernels are latency-bound: profiles/r01_sweep64_one_gpu.json)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 60; sweep64: steps per point, default 100)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["c3", "sweep64"], default="c3")
+    ap.add_argument("--scale", type=float, default=MESH_SCALE, help="factor on every mats.*.mesh (0.43 -> ~1.04M DOF)")
+    ap.add_argument("--cpu-steps", type=int, default=60, help="steps of the CPU baseline sample (0 = skip): with the LU factorisation ~10-15 s of host work")
+    ap.add_argument("--profile-steps", type=int, default=4, help="extra steps with in-situ SpMV event timing")
+    ap.add_argument("--precond", choices=["amg", "jacobi"], default="amg",
+                    help="PCG preconditioner of the timed run: smoothed-aggregation V-cycle (default) or plain Jacobi")
+    ap.add_argument("--jacobi-steps", type=int, default=10,
+                    help="with --precond amg: also time this many Jacobi-PCG steps for the record (0 = skip)")
+    ap.add_argument("--sweep-points", type=int, default=SWEEP_POINTS,
+                    help="c3 workload: also run this many kappa points of the C5 sweep as a side measurement (0 = skip)")
+    ap.add_argument("--sweep-concurrent", type=int, default=SWEEP_CONCURRENT)
+    ap.add_argument("--hbm-scale", type=float, default=HBM_SCALE,
+                    help="mesh factor of the HBM-resident roofline point (N = 1 only; 0 = skip)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="form the process group, report its size and exit: checks the launcher plumbing (no GPU work)")
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 100 if args.workload == "sweep64" else 60
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        ap.error("--gpus and --steps must be positive, --warmup non-negative")
+    return args
+
+
+def spawn_ranks(args, argv):
+    """--gpus N without an outside launcher: start the N ranks as a fresh child (this process has not
+    imported torch or touched HIP), forward its JSON line, return its exit code."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if p.returncode == 0 and lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+        return 0
+    sys.stderr.write(f"bench.py: the {args.gpus}-rank child run failed (exit code {p.returncode})\n")
+    return p.returncode or 1
 
 
 def build_problem_inputs(scale):
+    import yaml
     from heatflow_amd.geometry import build_stack, scale_mesh_sizes
     from heatflow_amd.mesh import Mesh
 
@@ -101,78 +164,278 @@ def cpu_baseline(cfg, mesh, n_sample_steps, first_step):
     }
 
 
-def main():
+class Ranks:
+    """The process group of this run (a world of one without torch.distributed)."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist, self.torch = None, None
+        self.backend, self.dev_index = "nccl", self.local_rank
+        if self.world > 1 or os.environ.get("HEATFLOW_BENCH_FORCE_DIST") == "1":   # the latter: rehearse the RCCL path on 1 GPU
+            import torch                      # torch first: its bundled HIP runtime must be the one both sides use
+            import torch.distributed as dist
+            # HEATFLOW_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
+            # (ranks share devices, the mesh travels through host tensors); the measured runs use RCCL
+            self.backend = os.environ.get("HEATFLOW_BENCH_BACKEND", "nccl")
+            ndev = torch.cuda.device_count()
+            if self.backend == "nccl" and ndev < int(os.environ.get("LOCAL_WORLD_SIZE", self.world)):
+                raise SystemExit(f"bench.py: {self.world} ranks but {ndev} GPU(s) visible: RCCL needs one GPU per rank "
+                                 "(HEATFLOW_BENCH_BACKEND=gloo rehearses the code path on fewer GPUs)")
+            self.dev_index = self.local_rank % max(ndev, 1)
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.dev_index)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index))
+            else:
+                if ndev > 0:
+                    torch.cuda.set_device(self.dev_index)
+                dist.init_process_group(self.backend)
+            self.dist, self.torch = dist, torch
+            self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def device(self):
+        return self.torch.device("cuda", self.dev_index) if self.backend == "nccl" else self.torch.device("cpu")
+
+    def barrier_sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.torch.cuda.is_available():
+                self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def run_sweep64(ranks, n_points, steps_per_point, warmup_steps, concurrent):
+    """BASELINE C5: `n_points` kappa_sample values on geballe_with_diamond at stock mesh size, point i ->
+    rank i mod world, mesh + tag map broadcast once, `concurrent` points in flight per rank
+    (reference parameter_sweep.py:423-446, sweep_test.py:47-115).  Returns the measurement (rank 0) or None."""
+    import shutil
+    import tempfile
+
+    import yaml
+    from heatflow_amd import parameter_sweep as ps
+
+    with open(os.path.join(ROOT, "cfgs", "geballe_with_diamond.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    dt0 = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
+    cfg["timing"]["num_steps"] = int(steps_per_point)
+    cfg["timing"]["t_final"] = dt0 * int(steps_per_point)        # steps 0..K-1 of the configured run, same dt
+    ks = ps.get_k_values(count=n_points)
+    tmp = tempfile.mkdtemp(prefix=f"hf_sweep64_r{ranks.rank}_")
+    clock, timing = {}, {}
+
+    def on_ready():
+        ranks.barrier_sync()
+        clock["t0"] = time.perf_counter()
+
+    def on_done():
+        clock["mine"] = time.perf_counter() - clock["t0"]
+        ranks.barrier_sync()
+        clock["all"] = time.perf_counter() - clock["t0"]
+
+    try:
+        t_all = time.perf_counter()
+        rows = ps.run_kappa_sweep(cfg, os.path.join(tmp, "mesh"), ks, os.path.join(tmp, "out"), rebuild_mesh=True,
+                                  device_id=ranks.dev_index, concurrent=concurrent, warmup_steps=warmup_steps,
+                                  on_ready=on_ready, on_done=on_done, timing=timing)
+        t_all = time.perf_counter() - t_all
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    wall = ranks.max_over_ranks(clock["all"])
+    if ranks.rank != 0:
+        return None
+    bad = [r for r in rows if r["status"] != "success"]
+    if bad:
+        raise SystemExit(f"bench.py: {len(bad)} sweep point(s) failed, first: {bad[0]['error']}")
+    import numpy as np
+    with open(os.path.join(ROOT, "cfgs", "geballe_with_diamond.yaml")) as f:
+        n_dof = _stock_dof(yaml.safe_load(f))
+    return {
+        "workload": (f"{n_points}-point kappa_sample sweep [{ks[0]}..{ks[-1]}] on cfgs/geballe_with_diamond.yaml, stock mesh "
+                     f"(BASELINE C5), point i -> rank i mod {ranks.world}, {concurrent} in flight per rank, "
+                     f"steps 0..{steps_per_point - 1} per point"),
+        "points": n_points, "n_dof": n_dof, "steps_per_point": steps_per_point, "concurrent_per_rank": concurrent,
+        "wall_s": wall, "value": n_points * n_dof * steps_per_point / wall, "unit": "DOF-updates/s",
+        "points_per_s": n_points / wall, "pcg_iters_per_step_mean": float(np.mean([r["pcg_iters_mean"] for r in rows])),
+        "rank0_phases_s": {k: timing.get(k) for k in ("mesh_s", "broadcast_s", "warmup_s", "points_s")},
+        "whole_call_s": t_all,
+    }
+
+
+_STOCK_DOF = {}
+
+
+def _stock_dof(cfg):
+    """Node count of the stock mesh (rank 0 built it a moment ago; meshing again is 0.2 s)."""
+    if "n" not in _STOCK_DOF:
+        from heatflow_amd.geometry import build_stack
+        from heatflow_amd.mesh import Mesh
+        st = build_stack(cfg)
+        _STOCK_DOF["n"] = len(Mesh("mesh.msh", st.bounds, st.materials).build_mesh().coords)
+    return _STOCK_DOF["n"]
+
+
+def kernel_rooflines(be, prob, hb, heated, first_step, profile_steps):
+    """Durations of the dominant kernels on the live operator, HIP events on the solver's own stream.
+    In-loop: kernel-attached start/stop events (hipExtLaunchKernelGGL) on the k_spmv<9> launches of
+    `profile_steps` extra time steps.  Back to back: 100 launches in a row (what a cache-resident working
+    set flatters).  Returns a dict of microseconds."""
+    out = {"spmv9_in_loop": None}
+    if profile_steps > 0:
+        be.set_profile(True)
+        prob.run(profile_steps, time_varying=heated, first_step=first_step)
+        ms_sum, cnt = be.get_profile()
+        be.set_profile(False)
+        if cnt > 0:
+            out["spmv9_in_loop"] = 1e3 * ms_sum / cnt
+            out["spmv9_in_loop_launches"] = int(cnt)
+    for nm, k in (("spmv9_back_to_back", hb.K_PCG_SPMV), ("update_back_to_back", hb.K_PCG_UPDATE),
+                  ("plain_spmv_back_to_back", hb.K_SPMV), ("stream_read", hb.K_STREAM_READ)):
+        out[nm] = 1e3 * be.time_kernel(k, 100)
+    return out
+
+
+def assembly_rooflines(be, prob, hb, n, ne, nnz):
+    """Element kernel variants: 20 back-to-back launches, and single launches with an SpMV pass in between
+    (what one launch costs when the previous kernel was something else, as in a kappa sweep)."""
+    import numpy as np
+    asm_bytes = 16 * ne + 16 * n + 16 * nnz           # SURVEY 8d: tri+tag, coords, each CSR value of M and A written once
+    res = {"bytes_per_launch": asm_bytes, "formula": "16*n_e + 16*n + 2*8*nnz (SURVEY 8d, M and A)"}
+    for name, mode in (("lds_atomic", hb.ASM_LDS_ATOMIC), ("lds_colored", hb.ASM_LDS_COLORED)) + \
+            ((("row_gather", hb.ASM_ROW_GATHER),) if hasattr(hb, "ASM_ROW_GATHER") else ()):
+        be.assemble(prob.dt, mode)
+        b2b = 1e3 * be.time_kernel(hb.K_ASSEMBLE, 20)
+        singles = []
+        for _ in range(7):
+            be.assemble(prob.dt, mode)
+            be.time_kernel(hb.K_SPMV, 2)
+            singles.append(1e3 * be.time_kernel(hb.K_ASSEMBLE, 1))
+        us1 = float(np.median(singles))
+        res[name] = {"us_back_to_back": b2b, "us_single_launch_median": us1,
+                     "achieved": asm_bytes / (us1 * 1e-6) / 1e9, "frac": asm_bytes / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "frac_back_to_back": asm_bytes / (b2b * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    res["default_mode"] = {0: "lds_atomic", 1: "lds_colored", 3: "row_gather"}.get(prob.assembly_mode, str(prob.assembly_mode))
+    be.assemble(prob.dt, prob.assembly_mode)          # restore the operator of the run
+    return res
+
+
+def hbm_resident_point(scale, dev_index, steps):
+    """The same kernels on a mesh whose operator is far larger than the 256 MiB Infinity Cache:
+    Jacobi-PCG steps (no multigrid set-up needed) with in-loop events, plus back-to-back figures."""
+    import numpy as np
+    from heatflow_amd import hip_backend as hb
+
+    t0 = time.perf_counter()
+    cfg, stack, mesh = build_problem_inputs(scale)
+    t_mesh = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    prob = make_problem(cfg, stack, mesh.coords, mesh.tris, mesh.tags, mesh.material_tags, None, dev_index, 0)
+    t_setup = time.perf_counter() - t0
+    be = prob.backend
+    try:
+        n, ne, nnz = be.n, be.n_e, be.nnz
+        for bc in prob.bcs:
+            bc.update(0.0)
+        heated = [prob.bcs[3]]
+        prob.run(5, time_varying=heated, first_step=0)              # reach the heated steps
+        be.set_profile(True)
+        _, _, iters = prob.run(steps, time_varying=heated, first_step=5)
+        ms_sum, cnt = be.get_profile()
+        be.set_profile(False)
+        us_loop = 1e3 * ms_sum / cnt if cnt else None
+        us = {nm: 1e3 * be.time_kernel(k, 20) for nm, k in
+              (("spmv9_back_to_back", hb.K_PCG_SPMV), ("update_back_to_back", hb.K_PCG_UPDATE),
+               ("plain_spmv_back_to_back", hb.K_SPMV), ("stream_read", hb.K_STREAM_READ))}
+        asm = assembly_rooflines(be, prob, hb, n, ne, nnz)
+        b9 = 12 * nnz + 44 * n
+        t9 = us_loop if us_loop else us["spmv9_back_to_back"]
+        return {
+            "workload": f"cfgs/geballe_with_diamond.yaml, every mats.*.mesh x {scale}", "n_dof": n, "nnz": nnz,
+            "matrix_bytes": 12 * nnz, "kernel": "k_spmv<9>", "bytes_per_launch": b9,
+            "us_per_launch_in_loop_events": us_loop, "in_loop_launches": int(cnt), "us_back_to_back": us,
+            "achieved": b9 / (t9 * 1e-6) / 1e9, "frac": b9 / (t9 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "plain_spmv_frac": (12 * nnz + 20 * n) / (us["plain_spmv_back_to_back"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "stream_read_GBs": 12 * nnz / (us["stream_read"] * 1e-6) / 1e9,
+            "assembly": asm, "jacobi_pcg_iters_per_step_mean": float(np.mean(iters)),
+            "host_setup_s": {"mesher": t_mesh, "set_mesh_assemble": t_setup},
+        }
+    finally:
+        prob.close()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+
     # stdout carries exactly ONE line (the JSON): everything else - RCCL's version banner, library
     # chatter - is sent to stderr by pointing fd 1 at fd 2 until the result is written
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scale", type=float, default=MESH_SCALE, help="factor on every mats.*.mesh (0.43 -> ~1.04M DOF)")
-    ap.add_argument("--cpu-steps", type=int, default=60, help="steps of the CPU baseline sample (0 = skip): with the LU factorisation ~10-15 s of host work")
-    ap.add_argument("--profile-steps", type=int, default=4, help="extra steps with in-situ SpMV event timing")
-    ap.add_argument("--precond", choices=["amg", "jacobi"], default="amg",
-                    help="PCG preconditioner of the timed run: smoothed-aggregation V-cycle (default) or plain Jacobi")
-    ap.add_argument("--jacobi-steps", type=int, default=10,
-                    help="with --precond amg: also time this many Jacobi-PCG steps for the record (0 = skip)")
-    args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    backend, dev_index = "nccl", local_rank
-    if world > 1 or os.environ.get("HEATFLOW_BENCH_FORCE_DIST") == "1":   # the latter: rehearse the RCCL path on 1 GPU
-        import torch                      # torch first: its bundled HIP runtime must be the one both sides use
-        import torch.distributed as dist
-        # HEATFLOW_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
-        # (ranks share devices, the mesh travels through host tensors); the measured runs use RCCL
-        backend = os.environ.get("HEATFLOW_BENCH_BACKEND", "nccl")
-        dev_index = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
+    ranks = Ranks(args)
+    world, rank, dev_index = ranks.world, ranks.rank, ranks.dev_index
+    if world != args.gpus and rank == 0:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}\n")
 
-    def barrier_sync():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
+    def emit(out):
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
-    # ---- mesh: built once (rank 0) and broadcast over RCCL, as a sweep shares it
+    if args.rendezvous_only:
+        total = ranks.max_over_ranks(float(rank)) + 1
+        if rank == 0:
+            emit({"rendezvous_only": True, "n_gpus": world, "max_rank_plus_1": int(total), "backend": ranks.backend if ranks.dist else None})
+        ranks.close()
+        return 0
+
+    import numpy as np
+    import yaml
+    from heatflow_amd import hip_backend as hb
+
+    common = {"unit": "DOF-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+              "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+
+    if args.workload == "sweep64":
+        sw = run_sweep64(ranks, SWEEP_POINTS, args.steps, args.warmup, args.sweep_concurrent)
+        if rank == 0:
+            out = dict(common, metric="DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond", value=sw["value"],
+                       ms_per_step=1e3 * sw["wall_s"] / args.steps, scaling="strong",
+                       config={"workload": sw["workload"], **{k: v for k, v in sw.items() if k not in ("workload", "value", "unit")}},
+                       roofline=None, cpu_baseline=None)
+            emit(out)
+        ranks.close()
+        return 0
+
+    # ---- mesh: built once (rank 0) and broadcast over RCCL with its tag map, as a sweep shares it (SURVEY 8e)
+    from heatflow_amd import parameter_sweep as ps
+    from heatflow_amd.geometry import build_stack, scale_mesh_sizes
+    arrays, mtags, mesh = ps._EMPTY_MESH, None, None
     if rank == 0:
         cfg, stack, mesh = build_problem_inputs(args.scale)
-        coords, tris, tags, mtags = mesh.coords, mesh.tris, mesh.tags, mesh.material_tags
-    if dist is not None:
-        import torch
-        from heatflow_amd.geometry import build_stack, scale_mesh_sizes
-        if rank != 0:
-            with open(os.path.join(ROOT, "cfgs", "geballe_with_diamond.yaml")) as f:
-                cfg = scale_mesh_sizes(yaml.safe_load(f), args.scale)
-            stack = build_stack(cfg)
-            mtags = {m.name: k + 1 for k, m in enumerate(stack.materials)}
-        dev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
-        sizes = torch.tensor([len(coords), len(tris)] if rank == 0 else [0, 0], dtype=torch.int64, device=dev)
-        dist.broadcast(sizes, 0)
-        n_, ne_ = int(sizes[0]), int(sizes[1])
-        tc = torch.from_numpy(coords).to(dev) if rank == 0 else torch.empty((n_, 2), dtype=torch.float64, device=dev)
-        tt = torch.from_numpy(tris).to(dev) if rank == 0 else torch.empty((ne_, 3), dtype=torch.int32, device=dev)
-        tg = torch.from_numpy(tags).to(dev) if rank == 0 else torch.empty((ne_,), dtype=torch.int32, device=dev)
-        for t in (tc, tt, tg):
-            dist.broadcast(t, 0)
-        coords, tris, tags = tc.cpu().numpy(), tt.cpu().numpy(), tg.cpu().numpy()
-        del tc, tt, tg
+        arrays, mtags = (mesh.coords, mesh.tris, mesh.tags), mesh.material_tags
+    else:
+        with open(os.path.join(ROOT, "cfgs", "geballe_with_diamond.yaml")) as f:
+            cfg = scale_mesh_sizes(yaml.safe_load(f), args.scale)
+        stack = build_stack(cfg)
+    (coords, tris, tags), mtags = ps.broadcast_mesh(arrays, mtags)
 
     k_sample = None if world == 1 else 3.8 + 0.02 * rank
     precond = 1 if args.precond == "amg" else 0
     prob = make_problem(cfg, stack, coords, tris, tags, mtags, k_sample, dev_index, precond)
     be = prob.backend
-    n, nnz = be.n, be.nnz
+    n, nnz, ne = be.n, be.nnz, be.n_e
     for bc in prob.bcs:
         bc.update(0.0)
     heated = [prob.bcs[3]]
@@ -180,45 +443,21 @@ def main():
     # ---- warm-up steps (untimed), then exactly K timed steps
     if args.warmup > 0:
         prob.run(args.warmup, time_varying=heated, first_step=0)
-    barrier_sync()
+    ranks.barrier_sync()
     t0 = time.perf_counter()
     _, _, iters = prob.run(args.steps, time_varying=heated, first_step=args.warmup)
-    barrier_sync()
+    ranks.barrier_sync()
     elapsed = time.perf_counter() - t0
     gpu_ms = be.last_gpu_ms()
-    if dist is not None:
-        import torch
-        tmax = torch.tensor([elapsed], dtype=torch.float64,
-                            device=torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu"))
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0])
+    elapsed = ranks.max_over_ranks(elapsed)
 
-    # ---- duration of the dominant kernel, two HIP-event measurements on the solver's own stream:
-    #  (a) 100 back-to-back launches of the kernel on the live matrix right after the timed region: this is the
-    #      number rocprofv3 reports for the same kernel inside the loop (its begin/end hardware timestamps);
-    #  (b) in the loop itself: kernel-attached start/stop events on launches of extra steps - these also
-    #      contain the ~4 us dependency gap to the previous kernel, so they read higher than (a) and rocprofv3.
-    #  roofline.achieved uses (a); (b) is reported beside it.
-    spmv_us_loop = None
-    if args.profile_steps > 0:
-        be.set_profile(True)
-        prob.run(args.profile_steps, time_varying=heated, first_step=args.warmup + args.steps)
-        ms_sum, cnt = be.get_profile()
-        be.set_profile(False)
-        if cnt > 0:
-            spmv_us_loop = 1e3 * ms_sum / cnt
-    # iteration-head kernel k_spmv<9>: vals 8 + colidx 4 per nnz; per row rowptr 4, z 8 (gathered operand),
-    # Ap 8+8 and p 8+8 (read-modify-write by the direction recurrence) = 12*nnz + 44*n
+    # ---- dominant kernel k_spmv<9>: vals 8 + colidx 4 per nnz; per row rowptr 4, z 8 (gathered operand),
+    # Ap 8+8 and p 8+8 (read-modify-write by the direction recurrence) = 12*nnz + 44*n (SURVEY 8d formula bytes)
+    k_us = kernel_rooflines(be, prob, hb, heated, args.warmup + args.steps, args.profile_steps)
     spmv_bytes = 12 * nnz + 44 * n
-    from heatflow_amd import hip_backend as hb
-    k_us = {nm: 1e3 * be.time_kernel(k, 100) for nm, k in
-            (("spmv", hb.K_PCG_SPMV), ("update", hb.K_PCG_UPDATE), ("plain_spmv", hb.K_SPMV))}
-    spmv_us = k_us["spmv"]
+    spmv_us = k_us["spmv9_in_loop"] if k_us["spmv9_in_loop"] else k_us["spmv9_back_to_back"]
     achieved = spmv_bytes / (spmv_us * 1e-6) / 1e9
-    # the device's own read ceiling on this operator's arrays ("measured device bandwidth on the box
-    # alongside the nominal 8 TB/s"): a plain 16-byte-load streaming read of values + column indices, 12*nnz bytes
-    read_us = 1e3 * be.time_kernel(hb.K_STREAM_READ, 100)
-    stream_gbs = 12 * nnz / (read_us * 1e-6) / 1e9
+    stream_gbs = 12 * nnz / (k_us["stream_read"] * 1e-6) / 1e9
     # HBM traffic of that kernel from the PMC passes kept under profiles/ (rocprofv3 cannot wrap itself):
     # only quoted when it was collected on exactly this matrix
     traffic = None
@@ -229,12 +468,16 @@ def main():
             traffic = pmc["kernels"]["k_spmv<9>"]["hbm_bytes"]
     except (OSError, KeyError, ValueError):
         pass
+    moved = traffic if traffic else 10 * nnz + 44 * n
+    amg_info = be.amg_info() if precond == 1 else None
+    asm_roof = None
+    if world == 1:
+        be.set_precond(0, False)          # the element kernel is timed without a multigrid set-up behind every re-assembly
+        asm_roof = assembly_rooflines(be, prob, hb, n, ne, nnz)
 
     # ---- for the record: the plain Jacobi-PCG loop (north-star solver) on the same steps
     jacobi = None
     if precond == 1 and args.jacobi_steps > 0 and world == 1:
-        amg_info = be.amg_info()
-        be.set_precond(0, False)
         be.assemble(prob.dt, prob.assembly_mode)
         prob.set_state(float(cfg["heating"]["ic_temp"]))
         if args.warmup > 0:
@@ -244,47 +487,59 @@ def main():
         tj = time.perf_counter() - tj
         jacobi = {"steps": args.jacobi_steps, "ms_per_step": 1e3 * tj / args.jacobi_steps,
                   "pcg_iters_per_step_mean": float(np.mean(itj)), "value": n * args.jacobi_steps / tj}
-    elif precond == 1:
-        amg_info = be.amg_info()
+    prob.close()
+
+    # ---- side measurements: the C5 sweep (every N), the HBM-resident roofline point (N = 1)
+    sweep = run_sweep64(ranks, args.sweep_points, 100, max(1, args.warmup), args.sweep_concurrent) if args.sweep_points > 0 else None
+    hbm = hbm_resident_point(args.hbm_scale, dev_index, 3) if (world == 1 and args.hbm_scale > 0) else None
 
     if rank == 0:
-        out = {
-            "metric": "DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond", "value": world * n * args.steps / elapsed,
-            "unit": "DOF-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfgs/geballe_with_diamond.yaml, every mats.*.mesh x {args.scale} (BASELINE C3, ~1M DOF), "
-                                   f"steps {args.warmup}..{args.warmup + args.steps - 1} of 100, dt=7.5e-8 s",
-                       "n_dof": n, "n_elem": be.n_e, "nnz": nnz, "n_dirichlet": be.n_bc,
-                       "solver": ("PCG + smoothed-aggregation multigrid V(1,1), damped-Jacobi smoothing" if precond
-                                  else "Jacobi-PCG"),
-                       "pcg_rtol": prob.rtol, "pcg_iters_per_step_mean": float(np.mean(iters)),
-                       "pcg_iters_per_step_max": int(np.max(iters)),
-                       "points": "1 sweep point per GPU (kappa_sample = 3.8 + 0.02*rank)" if world > 1 else "1 run",
-                       "gpu_ms_per_step_events": gpu_ms / args.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<9> (PCG iteration head: CSR SpMV with the direction update p, Ap fused; the column stream is 16-bit compressed, so the measured traffic is below the formula bytes)",
-                         "bytes_per_launch": spmv_bytes, "us_per_launch": spmv_us,
-                         "us_per_launch_in_loop_events": spmv_us_loop, "us_back_to_back": k_us,
-                         "measured_stream_read": {"GB/s": stream_gbs, "us": read_us, "bytes": 12 * nnz,
-                                                  "what": "16-byte-load read of the operator's values + column indices on this box",
-                                                  "frac_of_it": achieved / stream_gbs,
-                                                  "plain_spmv_frac_of_it": (12 * nnz + 20 * n) / (k_us["plain_spmv"] * 1e-6) / 1e9 / stream_gbs}},
-        }
+        out = dict(common, metric="DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond",
+                   value=world * n * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, scaling="weak")
+        out["config"] = {
+            "workload": f"cfgs/geballe_with_diamond.yaml, every mats.*.mesh x {args.scale} (BASELINE C3, ~1M DOF), "
+                        f"steps {args.warmup}..{args.warmup + args.steps - 1} of 100, dt=7.5e-8 s",
+            "n_dof": n, "n_elem": ne, "nnz": nnz, "n_dirichlet": be.n_bc,
+            "solver": ("PCG + smoothed-aggregation multigrid V(1,1), damped-Jacobi smoothing" if precond else "Jacobi-PCG"),
+            "pcg_rtol": prob.rtol, "pcg_iters_per_step_mean": float(np.mean(iters)), "pcg_iters_per_step_max": int(np.max(iters)),
+            "points": "1 sweep point per GPU (kappa_sample = 3.8 + 0.02*rank)" if world > 1 else "1 run",
+            "gpu_ms_per_step_events": gpu_ms / args.steps}
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel": "k_spmv<9> (PCG iteration head: CSR SpMV with the direction update p, Ap fused)",
+            "bytes_per_launch": spmv_bytes, "us_per_launch": spmv_us,
+            "timing": ("in-loop: kernel-attached HIP events on the k_spmv<9> launches of the time loop"
+                       if k_us["spmv9_in_loop"] else "back-to-back launches (no in-loop sample)"),
+            "cache_resident": bool(12 * nnz + 64 * n < 256 * 2**20),
+            "note": ("at this size the iteration's working set sits in the 256 MiB Infinity Cache: frac is against the HBM "
+                     "peak but is not an HBM measurement - see hbm_resident"),
+            "us_back_to_back": {k: v for k, v in k_us.items() if k.endswith("back_to_back")},
+            "frac_back_to_back": spmv_bytes / (k_us["spmv9_back_to_back"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "bytes_moved_per_launch": moved,
+            "frac_bytes_moved": moved / (spmv_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "bytes_moved_note": "PMC traffic when collected on this matrix, else 10*nnz + 44*n (16-bit column stream)",
+            "measured_stream_read": {"GB/s": stream_gbs, "us": k_us["stream_read"], "bytes": 12 * nnz,
+                                     "what": "16-byte-load read of the operator's values + column indices on this box",
+                                     "frac_of_it": achieved / stream_gbs},
+            "assembly": asm_roof, "hbm_resident": hbm}
         if precond == 1:
             out["config"]["amg"] = amg_info
         if jacobi is not None:
             out["config"]["jacobi_pcg"] = jacobi
+        if sweep is not None:
+            out["config"]["sweep64"] = sweep
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, mesh, args.cpu_steps, args.warmup)
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if jacobi is not None:
+                out["config"]["jacobi_pcg"]["gpu_over_cpu"] = jacobi["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
-    prob.close()
-    if dist is not None:
-        dist.destroy_process_group()
+        emit(out)
+    ranks.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

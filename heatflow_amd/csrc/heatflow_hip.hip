@@ -32,8 +32,7 @@ int hf_create(int device_id, hf_ctx** out) {
   auto bail = [&](int rc) { *out = ctx; return rc; };  // keep ctx so the caller can read the message
   if (hipSetDevice(device_id) != hipSuccess) return bail(fail(ctx, HF_ERR_HIP, "hipSetDevice(%d) failed", device_id));
   // non-blocking: no implicit ordering with the legacy stream, so contexts driven from different host
-  // threads (concurrent sweep points) do not serialise on it and graph capture on one cannot be broken
-  // by another thread's synchronous copy
+  // threads (concurrent sweep points) do not serialise on it
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(ctx, HF_ERR_HIP, "hipStreamCreate failed"));
   if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess)
@@ -48,7 +47,6 @@ int hf_create(int device_id, hf_ctx** out) {
   if (rc == HF_OK && (hipMemsetAsync(ctx->d_scal, 0, sizeof(Scal), ctx->stream) != hipSuccess ||
                       hipStreamSynchronize(ctx->stream) != hipSuccess))
     rc = fail(ctx, HF_ERR_HIP, "hipMemset failed");
-  if (const char* e = std::getenv("HEATFLOW_GRAPH")) ctx->use_graph = (e[0] == '1');
   *out = ctx;
   return rc;
 }
@@ -67,7 +65,6 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_M1); dev_free(&ctx->d_dinv1); dev_free(&ctx->d_gz); dev_free(&ctx->d_gr); dev_free(&ctx->d_bz); dev_free(&ctx->d_br);
   dev_free(&ctx->d_tmp); dev_free(&ctx->d_part_pAp); dev_free(&ctx->d_part_rz); dev_free(&ctx->d_part_zz);
   dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp);
-  drop_graphs(ctx);
   for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -336,7 +333,6 @@ int hf_flux_setup(hf_ctx* ctx) {
   if (!ctx->have_mesh) return fail(ctx, HF_ERR_STATE, "hf_flux_setup before hf_set_mesh");
   HF_HIP(hipSetDevice(ctx->dev));
   const int n = ctx->n;
-  drop_graphs(ctx);
   HF_TRY(dev_alloc(ctx, &ctx->d_M1, ctx->nnz));
   HF_TRY(dev_alloc(ctx, &ctx->d_dinv1, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_gz, n));

@@ -146,12 +146,6 @@ struct hf_ctx {
   int flux_valid = 0;          // components (bit 0 z, bit 1 r) the last projection solved
   double *d_M1 = nullptr, *d_dinv1 = nullptr, *d_gz = nullptr, *d_gr = nullptr, *d_bz = nullptr, *d_br = nullptr;
   int pred_flux[2] = {0, 0};
-  // hipGraph replay of the PCG loops: one executable graph per (system, preconditioner), each holding
-  // an even number of iterations (all host-side pointer swaps return to their start after two)
-  struct IterGraph { const double* A; const double* dinv; double* x; const double* b; bool amg; int iters; hipGraphExec_t exec; };
-  std::vector<IterGraph> graphs;
-  bool use_graph = false;      // opt-in (HEATFLOW_GRAPH=1): on this stack the loop is device-bound, replay measured no gain,
-                               // and rocprofv3 --kernel-trace crashes on long runs of graph replays
   // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
@@ -198,7 +192,7 @@ int dev_alloc(hf_ctx* ctx, T** p, size_t count) {
 #define HF_TRY(expr) do { int rc_ = (expr); if (rc_ != HF_OK) return rc_; } while (0)
 
 // Host<->device copy that is complete on return, issued on the context's own stream (never the legacy
-// stream: contexts on other threads may be capturing graphs, which a legacy-stream copy would break).
+// stream: contexts driven from other host threads must not serialise on it).
 hipError_t copy_sync(hf_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 
 template <typename T>

@@ -12,10 +12,7 @@ using DevLevel = hf_ctx::DevLevel;
 
 void free_dev_csr(DevCsr& m) { dev_free(&m.ptr); dev_free(&m.idx); dev_free(&m.val); m = DevCsr(); }
 
-void drop_graphs(hf_ctx* ctx);
-
 void free_amg(hf_ctx* ctx) {
-  drop_graphs(ctx);
   for (size_t l = 0; l < ctx->amg.size(); ++l) {
     DevLevel& L = ctx->amg[l];
     if (l > 0) { free_dev_csr(L.A); dev_free(&L.dinv); dev_free(&L.x); dev_free(&L.cat); }
@@ -192,8 +189,7 @@ void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
 #undef HF_VEC
 }
 
-// z = B r: one V(1,1) cycle.  Fixed buffer roles (no pointer swaps, so captured graphs and eager
-// launches always agree): on entry d_z holds w0 D^-1 r (written by the update / start kernel); on exit
+// z = B r: one V(1,1) cycle.  Fixed buffer roles (no pointer swaps): on entry d_z holds w0 D^-1 r (written by the update / start kernel); on exit
 // d_z2 holds z and part_rz[out_slot] the partials of r.z.  The finest level runs its two sweeps explicitly
 // (its operator changes with every re-assembly); every intermediate level is two launches, the fused
 // down leg Rt and the fused up leg GP (amg_host.hpp), the coarsest level a dense mat-vec.
@@ -253,44 +249,6 @@ int read_scal(hf_ctx* ctx) {
   return HF_OK;
 }
 
-void drop_graphs(hf_ctx* ctx) {
-  for (auto& g : ctx->graphs)
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  ctx->graphs.clear();
-}
-
-// Executable graph holding `iters` (even) consecutive iterations of the loop for `sys`; captured on
-// first use, replayed afterwards.  Returns nullptr when capture is unavailable (the caller then
-// launches eagerly).
-hipGraphExec_t iteration_graph(hf_ctx* ctx, const LinSys& sys, bool use_amg, int iters) {
-  for (auto& g : ctx->graphs)
-    if (g.A == sys.A && g.dinv == sys.dinv && g.x == sys.x && g.b == sys.b && g.amg == use_amg && g.iters == iters)
-      return g.exec;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  const bool dbg = std::getenv("HEATFLOW_DEBUG") != nullptr;
-  if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-    if (dbg) fprintf(stderr, "[heatflow] graph capture could not start\n");
-    return nullptr;
-  }
-  for (int k = 0; k < iters; ++k) {
-    if (use_amg) launch_amg_iteration(ctx, sys.x, k & 1);
-    else launch_pcg_iteration(ctx, sys, k & 1);
-  }
-  if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || graph == nullptr) {
-    if (dbg) fprintf(stderr, "[heatflow] graph capture failed\n");
-    return nullptr;
-  }
-  const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  size_t nnodes = 0;
-  (void)hipGraphGetNodes(graph, nullptr, &nnodes);
-  (void)hipGraphDestroy(graph);
-  if (dbg) fprintf(stderr, "[heatflow] graph of %d iterations: %zu nodes, instantiate %s\n", iters, nnodes, hipGetErrorString(e));
-  if (e != hipSuccess) return nullptr;
-  ctx->graphs.push_back({sys.A, sys.dinv, sys.x, sys.b, use_amg, iters, exec});
-  return exec;
-}
-
 // PCG on `sys` started from sys.x.  Jacobi: any system on the pattern; AMG: the main system only.
 // Iteration count / residual are left in h_scal; *pred carries the burst-size hint between calls.
 int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double atol, int max_it, int* pred) {
@@ -320,19 +278,11 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
   // first burst: what the previous solve needed (the counts drift slowly), then check in small bursts
   int burst = std::max(1, std::min(max_it, *pred > 0 ? *pred : (use_amg ? 8 : 32)));
   if (trace_res) burst = 2;
-  // graph unit: 2 multigrid iterations (~40 kernels) or 16 Jacobi iterations (48 kernels) per replay
-  const int unit = use_amg ? 2 : 16;
-  hipGraphExec_t gexec = (ctx->use_graph && !ctx->prof) ? iteration_graph(ctx, sys, use_amg, unit) : nullptr;
   while (true) {
     ctx->prof_base = launched;
-    if (gexec != nullptr) {
-      burst = ((burst + unit - 1) / unit) * unit;
-      for (int k = 0; k < burst; k += unit) HF_HIP(hipGraphLaunch(gexec, ctx->stream));
-    } else {
-      for (int k = 0; k < burst; ++k) {
-        if (use_amg) launch_amg_iteration(ctx, sys.x, (launched + k) & 1);
-        else launch_pcg_iteration(ctx, sys, (launched + k) & 1);
-      }
+    for (int k = 0; k < burst; ++k) {
+      if (use_amg) launch_amg_iteration(ctx, sys.x, (launched + k) & 1);
+      else launch_pcg_iteration(ctx, sys, (launched + k) & 1);
     }
     launched += burst;
     HF_HIP(hipGetLastError());
@@ -439,7 +389,7 @@ int step_device(hf_ctx* ctx, const double* g_host, const double* g_dev, double r
   // pass writes the extrapolated start vector 2 u^n - u^{n-1}, and the three state buffers rotate
   if (ctx->extrapolate && ctx->have_prev) {
     launch_spmv<8>(ctx, ctx->d_M, ctx->d_u, ctx->d_b, nullptr, ctx->d_uprev, ctx->d_ustart);
-    // u^{n-1} <- u^n, iterate <- start vector (copies, not pointer rotation: captured graphs hold d_u)
+    // u^{n-1} <- u^n, iterate <- start vector
     HF_HIP(hipMemcpyAsync(ctx->d_uprev, ctx->d_u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
     if (ra.k > 0)
       hipLaunchKernelGGL(k_start_vector, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, ctx->d_ustart, ra, ctx->d_u);

@@ -22,6 +22,7 @@ from __future__ import annotations
 import contextlib
 import copy
 import csv
+import hashlib
 import json
 import os
 import sys
@@ -172,7 +173,9 @@ class SimulationSession:
                                       value=heat_o.gaussian))
         varying = bcs[3:]
         tag_to_k, tag_to_rc = self._tables(stack)
-        key = (dt, tuple(sorted(tag_to_rc.items())), tuple(int(b.row_dofs.sum()) for b in bcs))
+        # the resident problem is reusable only for exactly the same Dirichlet DOF sets, in the same order
+        key = (dt, tuple(sorted(tag_to_rc.items())),
+               tuple(hashlib.sha1(np.ascontiguousarray(b.row_dofs, dtype=np.int64).tobytes()).hexdigest() for b in bcs))
         if self.problem is None or key != self._key:
             self.close()
             print("Assigning material properties...")

@@ -391,12 +391,16 @@ class Mesh:
         return self
 
     # -- I/O ----------------------------------------------------------------------------
-    def write(self, filename: str):
-        """Write the mesh.  ``*.msh`` -> Gmsh MSH 2.2 ASCII (readable by gmsh and by
-        :func:`read_msh`) plus a binary ``.npz`` sidecar for fast reload."""
+    def write(self, filename: str, version: str = "2.2"):
+        """Write the mesh.  ``*.msh`` -> Gmsh ASCII, MSH 2.2 (default, native writer) or MSH 4.1 (the
+        format the reference's ``gmsh.write`` produces, mesh.py:191-195); both are readable by gmsh and
+        by :func:`read_msh`.  A binary ``.npz`` sidecar is written beside it for fast reload."""
         if self.coords is None:
             raise RuntimeError("Mesh not built - call build_mesh() first.")
-        write_msh(filename, self.coords, self.tris, self.tags, self.material_tags)
+        if str(version).startswith("4"):
+            write_msh41(filename, self.coords, self.tris, self.tags, self.material_tags)
+        else:
+            write_msh(filename, self.coords, self.tris, self.tags, self.material_tags)
         np.savez(os.path.splitext(filename)[0] + ".npz", coords=self.coords, tris=self.tris, tags=self.tags)
 
 
@@ -423,6 +427,58 @@ def write_msh(filename, coords, tris, tags, names=None):
         eid = np.arange(1, ne + 1)
         rows = np.column_stack([eid, np.full(ne, 2), np.full(ne, 2), tags, tags, tris + 1])
         np.savetxt(f, rows, fmt="%d")
+        f.write("$EndElements\n")
+
+
+def write_msh41(filename, coords, tris, tags, names=None, surface_ids=None):
+    """Gmsh MSH 4.1 ASCII as ``gmsh.write`` lays it out for the reference's meshes (one plane surface per
+    material, one physical group per surface, mesh.py:114-126): $PhysicalNames, $Entities (surfaces only,
+    each with its bounding box and its physical tag), $Nodes and $Elements in one block per surface.
+    ``tags`` are the physical tags (= cell tags); ``surface_ids`` {physical tag: surface entity id} lets a
+    caller separate the two numberings (default: the same number).  Every node is listed once, in the block
+    of the lowest-numbered surface that uses it (gmsh files interface nodes under curve / point entities,
+    which carry no cells; readers only need each node exactly once)."""
+    coords = np.asarray(coords, dtype=np.float64)
+    tris = np.asarray(tris, dtype=np.int64)
+    tags = np.asarray(tags, dtype=np.int64)
+    phys = [int(t) for t in np.unique(tags)]
+    sid = {t: int(surface_ids[t]) if surface_ids else t for t in phys}
+    order = sorted(phys, key=lambda t: sid[t])
+    n, ne = len(coords), len(tris)
+    owner = np.full(n, -1, dtype=np.int64)
+    for t in reversed(order):                                  # the lowest surface id wins
+        owner[np.unique(tris[tags == t])] = sid[t]
+    if (owner < 0).any():
+        raise MeshError("write_msh41: a node belongs to no triangle")
+    with open(filename, "w") as f:
+        f.write("$MeshFormat\n4.1 0 8\n$EndMeshFormat\n")
+        if names:
+            inv = {int(v): k for k, v in names.items()}
+            f.write(f"$PhysicalNames\n{len(phys)}\n")
+            for t in phys:
+                f.write(f'2 {t} "{inv.get(t, "surface_%d" % t)}"\n')
+            f.write("$EndPhysicalNames\n")
+        f.write(f"$Entities\n0 0 {len(order)} 0\n")
+        for t in order:
+            p = coords[np.unique(tris[tags == t])]
+            lo, hi = p.min(axis=0), p.max(axis=0)
+            f.write(f"{sid[t]} {float(lo[0])!r} {float(lo[1])!r} 0 {float(hi[0])!r} {float(hi[1])!r} 0 1 {t} 0\n")
+        f.write("$EndEntities\n")
+        f.write(f"$Nodes\n{len(order)} {n} 1 {n}\n")
+        for t in order:
+            idx = np.nonzero(owner == sid[t])[0]
+            f.write(f"2 {sid[t]} 0 {len(idx)}\n")
+            if len(idx):
+                np.savetxt(f, idx + 1, fmt="%d")
+                np.savetxt(f, np.column_stack([coords[idx], np.zeros(len(idx))]), fmt="%.17g %.17g %.17g")
+        f.write("$EndNodes\n")
+        f.write(f"$Elements\n{len(order)} {ne} 1 {ne}\n")
+        at = 1
+        for t in order:
+            sel = np.nonzero(tags == t)[0]
+            f.write(f"2 {sid[t]} 2 {len(sel)}\n")
+            np.savetxt(f, np.column_stack([np.arange(at, at + len(sel)), tris[sel] + 1]), fmt="%d")
+            at += len(sel)
         f.write("$EndElements\n")
 
 

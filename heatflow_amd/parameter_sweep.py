@@ -81,12 +81,15 @@ def world_info():
     return (d.get_rank(), d.get_world_size()) if d is not None else (0, 1)
 
 
-def broadcast_mesh(arrays, src=0):
-    """Broadcast (coords f64 (n,2), tris i32 (ne,3), tags i32 (ne,)) from ``src`` to all ranks.
-    With the nccl backend the tensors travel GPU-to-GPU (RCCL over xGMI); with gloo on the host."""
+def broadcast_mesh(arrays, tag_map=None, src=0):
+    """Broadcast (coords f64 (n,2), tris i32 (ne,3), tags i32 (ne,)) and the material tag map
+    {material name: cell tag} from ``src`` to all ranks; returns (arrays, tag_map).  The tag map
+    belongs to the mesh (``mesh_cfg.yaml``: gmsh surface ids for a reference-written mesh, list
+    positions for ours), so every rank must use rank ``src``'s copy and never guess it.
+    With the nccl backend the arrays travel GPU-to-GPU (RCCL over xGMI), with gloo on the host."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
-        return arrays
+        return arrays, tag_map
     import torch
 
     on_gpu = d.get_backend() == "nccl"
@@ -99,12 +102,17 @@ def broadcast_mesh(arrays, src=0):
     out = []
     for k, (shape, dtype) in enumerate(shapes):
         if rank == src:
-            t = torch.from_numpy(np.ascontiguousarray(arrays[k])).to(dev)
+            t = torch.from_numpy(np.ascontiguousarray(arrays[k], dtype=np.float64 if k == 0 else np.int32)).to(dev)
         else:
             t = torch.empty(shape, dtype=dtype, device=dev)
         d.broadcast(t, src)
         out.append(t.cpu().numpy())
-    return tuple(out)
+    box = [dict(tag_map) if rank == src else None]
+    d.broadcast_object_list(box, src)
+    return tuple(out), box[0]
+
+
+_EMPTY_MESH = (np.zeros((0, 2)), np.zeros((0, 3), np.int32), np.zeros(0, np.int32))
 
 
 def shard(items, rank, world):
@@ -172,14 +180,13 @@ def run_parameter_sweep(base_config_path, output_dir, fwhm_range, k_range, width
         mesh_folder = get_mesh_folder_for_width(base_mesh_folder, width)
         cfg0 = modify_config_for_parameters(base_config, group[0]["fwhm"], group[0]["k"], width)
         stack0 = build_stack(cfg0)
-        arrays, tag_map = None, {m.name: k + 1 for k, m in enumerate(stack0.materials)}
+        arrays, tag_map = _EMPTY_MESH, None
         if rank == 0:
             have = os.path.exists(os.path.join(mesh_folder, "mesh.msh")) and \
                 os.path.exists(os.path.join(mesh_folder, "mesh_cfg.yaml"))
             coords, tris, tags, tag_map = prepare_mesh(cfg0, mesh_folder, not have, stack0)
             arrays = (coords, tris, tags)
-        arrays = broadcast_mesh(arrays if arrays is not None else (np.zeros((0, 2)), np.zeros((0, 3), np.int32),
-                                                                   np.zeros(0, np.int32)))
+        arrays, tag_map = broadcast_mesh(arrays, tag_map)
         if session_factory is not None:
             session = session_factory(*arrays, tag_map)
         else:
@@ -232,36 +239,50 @@ def get_k_values(k0=3.8, half_width=0.5, step=0.02, count=None):
 
 
 def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=False, session_factory=None,
-                    device_id=None, exp_csv=None, concurrent=1):
-    """k_sample sweep on one mesh: point i -> rank i mod world; the mesh is broadcast once, each
-    rank keeps it resident and only re-values A per point.  Returns rows [{k, rmse, runtime,...}]
+                    device_id=None, exp_csv=None, concurrent=1, warmup_steps=0, on_ready=None, on_done=None,
+                    timing=None):
+    """k_sample sweep on one mesh: point i -> rank i mod world; the mesh (arrays + tag map) is broadcast
+    once, each rank keeps it resident and only re-values A per point.  Returns rows [{k, rmse, runtime,...}]
     (rmse of the normalised o-side watcher against the experiment, sweep_test.py:76-93).
 
     ``concurrent`` > 1 runs that many of a rank's points at once, each on its own solver context
     (own HIP stream, own copy of the mesh): at stock mesh sizes one point cannot fill an MI355X
-    (its kernels are latency-bound), so overlapping points raises the per-GPU throughput."""
+    (its kernels are latency-bound), so overlapping points raises the per-GPU throughput.
+
+    Measurement hooks (bench.py): ``warmup_steps`` > 0 makes every session run that many untimed steps of the
+    first point before the point loop (mesh, pattern, matrices and multigrid levels are then resident);
+    ``on_ready()`` / ``on_done()`` are called right before / after the point loop (barrier + clock);
+    ``timing`` (dict) receives the wall times of the phases on this rank."""
     from .analysis_utils import calculate_rmse
 
     rank, world = world_info()
     if device_id is None:
         device_id = int(os.environ.get("LOCAL_RANK", "0"))
     stack = build_stack(cfg)
-    arrays, tag_map = None, {m.name: k + 1 for k, m in enumerate(stack.materials)}
+    t_phase = time.perf_counter()
+    arrays, tag_map = _EMPTY_MESH, None
     if rank == 0:
         coords, tris, tags, tag_map = prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack)
         arrays = (coords, tris, tags)
         os.makedirs(output_dir, exist_ok=True)
-    arrays = broadcast_mesh(arrays if arrays is not None else (np.zeros((0, 2)), np.zeros((0, 3), np.int32),
-                                                               np.zeros(0, np.int32)))
+    if timing is not None:
+        timing["mesh_s"] = time.perf_counter() - t_phase
+    t_phase = time.perf_counter()
+    arrays, tag_map = broadcast_mesh(arrays, tag_map)
+    if timing is not None:
+        timing["broadcast_s"] = time.perf_counter() - t_phase
     session = session_factory(*arrays, tag_map) if session_factory else SimulationSession(*arrays, tag_map,
                                                                                         device_id=device_id)
     exp = None
     if exp_csv is not None:
         exp = np.genfromtxt(exp_csv, delimiter=",", names=True)
+    # folder per point as sweep_test.py:63 names it ("3.80"); more digits only if two points would share a folder
+    digits = 2 if len({f"{k:.2f}" for k in k_values}) == len(list(k_values)) else 4
+
     def one_point(k, sess):
         c = copy.deepcopy(cfg)
         c["mats"]["p_sample"]["k"] = float(k)
-        outdir = os.path.join(output_dir, f"{k:.2f}")
+        outdir = os.path.join(output_dir, f"{k:.{digits}f}")
         t0 = time.time()
         row = {"k": float(k), "rmse": float("nan"), "runtime": 0.0, "status": "failed", "error": None, "rank": rank}
         try:
@@ -284,13 +305,28 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
     sessions = [session]
     rows = []
     try:
-        if concurrent > 1 and len(mine) > 1:
+        n_sess = min(concurrent, len(mine)) if concurrent > 1 else 1
+        for _ in range(max(n_sess, 1) - 1):
+            sessions.append(session_factory(*arrays, tag_map) if session_factory
+                            else SimulationSession(*arrays, tag_map, device_id=device_id))
+        if warmup_steps > 0 and len(k_values):
+            t_phase = time.perf_counter()
+            cw = copy.deepcopy(cfg)
+            dt0 = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
+            cw["timing"]["num_steps"] = int(warmup_steps)
+            cw["timing"]["t_final"] = dt0 * int(warmup_steps)          # same dt: the resident problem is reused
+            cw["mats"]["p_sample"]["k"] = float(list(k_values)[0])
+            for sess in sessions:
+                sess.run(cw, build_stack(cw), get_watcher_points(cw))
+            if timing is not None:
+                timing["warmup_s"] = time.perf_counter() - t_phase
+        if on_ready is not None:
+            on_ready()
+        t_phase = time.perf_counter()
+        if len(sessions) > 1:
             import queue
             from concurrent.futures import ThreadPoolExecutor
 
-            for _ in range(min(concurrent, len(mine)) - 1):
-                sessions.append(session_factory(*arrays, tag_map) if session_factory
-                                else SimulationSession(*arrays, tag_map, device_id=device_id))
             free = queue.Queue()
             for sess in sessions:
                 free.put(sess)
@@ -306,6 +342,12 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
                 rows = list(pool.map(task, mine))
         else:
             rows = [one_point(k, session) for k in mine]
+        if on_done is not None:
+            on_done()
+        if timing is not None:
+            timing["points_s"] = time.perf_counter() - t_phase
+            timing["points_here"] = len(mine)
+            timing["sessions"] = len(sessions)
     finally:
         for sess in sessions:
             sess.close()

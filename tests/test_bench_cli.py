@@ -1,0 +1,47 @@
+"""bench.py's launcher plumbing on a box without GPUs: `--gpus N` starts the N ranks itself (fresh child
+before torch / HIP is touched), forwards one JSON line and reports the world size the process group has."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, **env):
+    e = dict(os.environ, OMP_NUM_THREADS="1", **env)
+    e.pop("WORLD_SIZE", None)
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=e, timeout=600)
+
+
+def test_gpus_2_self_spawns_two_ranks_and_reports_them():
+    p = _run(["--gpus", "2", "--rendezvous-only"], HEATFLOW_BENCH_BACKEND="gloo")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                                   # exactly one JSON line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["max_rank_plus_1"] == 2 and out["backend"] == "gloo"
+
+
+def test_gpus_1_needs_no_launcher():
+    p = _run(["--gpus", "1", "--rendezvous-only"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert json.loads(p.stdout.strip())["n_gpus"] == 1
+
+
+def test_more_ranks_than_gpus_fails_loudly_with_rccl():
+    """RCCL needs one GPU per rank: without them the run must exit non-zero, not report n_gpus: 1."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs are present")
+    p = _run(["--gpus", "2", "--rendezvous-only"])
+    assert p.returncode != 0 and not p.stdout.strip()
+    assert "GPU(s) visible" in p.stderr
+
+
+def test_bad_arguments_are_rejected():
+    p = _run(["--gpus", "0"])
+    assert p.returncode != 0

@@ -205,3 +205,107 @@ def test_sweep_world_size_2_gloo_shards_points_and_broadcasts_the_mesh(tmp_path)
         wa = np.genfromtxt(os.path.join(a["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
         wb = np.genfromtxt(os.path.join(b["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
         assert np.array_equal(wa["oside"], wb["oside"]) and np.array_equal(wa["pside"], wb["pside"])
+
+
+KAPPA_WORKER = textwrap.dedent("""
+    import os, sys, json, yaml
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import torch.distributed as dist
+    from heatflow_amd import parameter_sweep as ps
+    from test_driver_sweep_cpu import _session_factory
+    dist.init_process_group("gloo")
+    cfg = yaml.safe_load(open({cfg!r}))
+    timing = {{}}
+    rows = ps.run_kappa_sweep(cfg, {mesh!r}, [3.3, 3.6, 3.9, 4.2], {out!r}, session_factory=_session_factory,
+                              concurrent=2, warmup_steps=2, timing=timing)
+    if dist.get_rank() == 0:
+        json.dump({{"rows": rows, "timing": timing}}, open({res!r}, "w"))
+    dist.destroy_process_group()
+""")
+
+
+def test_kappa_sweep_world_size_2_uses_rank0s_tag_map_for_a_cached_mesh(tmp_path):
+    """A cached mesh.msh + mesh_cfg.yaml whose material tags are NOT the list positions (as a gmsh /
+    reference-written mesh has them: physical-group ids): rank 0 reads the tag map from mesh_cfg.yaml and
+    broadcasts it with the arrays; rank 1 must not guess {name: k+1}.  Two ranks, two points in flight
+    each, the measurement hooks on; the watcher curves equal a single-process run on the original tags."""
+    from heatflow_amd.driver import prepare_mesh
+    from heatflow_amd.geometry import build_stack
+    from heatflow_amd.mesh import write_msh41
+
+    cfg = _cfg("geballe_with_diamond", 16.0, 10)
+    cfg["heating"]["file"] = os.path.join(ROOT, cfg["heating"]["file"])
+    stack = build_stack(cfg)
+    m1 = str(tmp_path / "mesh1")
+    coords, tris, tags, tag_map = prepare_mesh(cfg, m1, True, stack)
+    rows1 = ps.run_kappa_sweep(cfg, m1, [3.3, 3.6, 3.9, 4.2], str(tmp_path / "out1"), session_factory=_session_factory)
+    assert [r["status"] for r in rows1] == ["success"] * 4
+    # the same mesh with permuted tags, written as MSH 4.1 without an npz sidecar (forces the reader)
+    perm = {t: 20 - t for t in tag_map.values()}
+    m2 = str(tmp_path / "mesh2")
+    os.makedirs(m2)
+    write_msh41(os.path.join(m2, "mesh.msh"), coords, tris, np.array([perm[t] for t in tags]),
+                {nm: perm[t] for nm, t in tag_map.items()})
+    mcfg = copy.deepcopy(cfg)
+    mcfg["material_tags"] = {nm: perm[t] for nm, t in tag_map.items()}
+    with open(os.path.join(m2, "mesh_cfg.yaml"), "w") as f:
+        yaml.safe_dump(mcfg, f)
+    cfg_path, res = str(tmp_path / "cfg.yaml"), str(tmp_path / "res.json")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    script = tmp_path / "kworker.py"
+    script.write_text(KAPPA_WORKER.format(root=ROOT, cfg=cfg_path, mesh=m2, out=str(tmp_path / "out2"), res=res))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", str(script)]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    got = json.load(open(res))
+    assert [r["status"] for r in got["rows"]] == ["success"] * 4, got["rows"]
+    assert [r["rank"] for r in got["rows"]] == [0, 1, 0, 1]
+    assert got["timing"]["sessions"] == 2 and got["timing"]["points_here"] == 2 and got["timing"]["warmup_s"] > 0
+    for r in got["rows"]:
+        a = np.genfromtxt(os.path.join(str(tmp_path / "out1"), f"{r['k']:.2f}", "watcher_points.csv"), delimiter=",", names=True)
+        b = np.genfromtxt(os.path.join(str(tmp_path / "out2"), f"{r['k']:.2f}", "watcher_points.csv"), delimiter=",", names=True)
+        # same physics on a renumbered mesh (the 4.1 file is re-ordered on load): direct solves agree to rounding.
+        # (Only the o-side watcher is compared: the p-side point lies midway between two nodes of this coarse
+        # mesh, and which of the two is "nearest" depends on the node numbering.)
+        assert np.abs(a["oside"] - b["oside"]).max() < 1e-8
+        assert np.abs(a["oside"] - 300.0).max() > 1e-6          # the heating has reached the watcher
+
+
+def test_session_is_not_reused_for_a_different_dirichlet_set_with_the_same_dof_sum(tmp_path):
+    """The resident problem is keyed on the Dirichlet DOF sets themselves: two sets with equal sums
+    (what the key used to fingerprint) must not share a HeatProblem."""
+    import heatflow_amd.driver as drv
+    from heatflow_amd.driver import SimulationSession, prepare_mesh
+    from heatflow_amd.geometry import build_stack
+
+    cfg = _cfg("geballe_with_diamond", 16.0, 3)
+    stack = build_stack(cfg)
+    coords, tris, tags, tag_map = prepare_mesh(cfg, str(tmp_path / "m"), True, stack)
+    be = OracleBackend()
+    sess = SimulationSession(coords, tris, tags, tag_map, backend=be)
+    sess.run(cfg, stack, watcher_points(cfg))
+    key1, dofs1 = sess._key, sess.problem.bc_dofs.copy()
+    real = drv.RowDirichletBC
+
+    class SameSum(real):                        # heated line: two DOFs swapped for two others with the same sum
+        def __init__(self, V, location, **kw):
+            super().__init__(V, location, **kw)
+            if location == "x":
+                d = self.row_dofs.astype(np.int64)
+                have, total = set(d.tolist()), int(d[0] + d[1])
+                a = next(a for a in range(len(coords)) if a not in have and total - a not in have
+                         and 0 <= total - a < len(coords) and a != total - a)
+                d[0], d[1] = a, total - a
+                self.row_dofs = np.sort(d).astype(np.int32)
+                self.dof_coords = self.V.coords[self.row_dofs]
+
+    drv.RowDirichletBC = SameSum
+    try:
+        sess.run(cfg, stack, watcher_points(cfg))
+    finally:
+        drv.RowDirichletBC = real
+    assert sess._key != key1 and sess._key[:2] == key1[:2]
+    assert int(dofs1.sum()) == int(sess.problem.bc_dofs.sum()) and not np.array_equal(dofs1, sess.problem.bc_dofs)
+    assert be.set_mesh_calls == 2               # a new HeatProblem was built for the new Dirichlet set

@@ -196,3 +196,46 @@ def test_c4_stock_read_flux_matches_oracle(hip, c2):
         assert scale > 1e6 and prob.backend.last_flux_iters.max() < 100
     finally:
         prob.close()
+
+
+def test_c5_sixty_four_point_kappa_sweep_on_one_gpu(hip, tmp_path):
+    """BASELINE C5 at its stated size on one GPU (a world of 1 takes all 64 points, 4 in flight): 64
+    kappa_sample values on the stock geballe_with_diamond mesh, 100 steps each (reference
+    parameter_sweep.py:423-446, sweep_test.py:47-115).  Every point must succeed; three of them (both ends
+    and the middle of the grid) are re-run by the oracle on the same mesh and compared at every step."""
+    import copy
+    import yaml
+    from conftest import HEATING_CSV, load_cfg
+    from heatflow_amd import parameter_sweep as ps
+    from heatflow_amd.geometry import watcher_points
+    from heatflow_amd.mesh import load_mesh_arrays
+    from heatflow_amd.solver import nearest_nodes
+    from oracle import heat_oracle as ho
+
+    cfg = load_cfg("geballe_with_diamond")
+    cfg["heating"]["file"] = HEATING_CSV
+    ks = ps.get_k_values(count=64)
+    assert len(ks) == 64 and len(set(ks.tolist())) == 64
+    mesh_folder, out = str(tmp_path / "mesh"), str(tmp_path / "out")
+    timing = {}
+    rows = ps.run_kappa_sweep(cfg, mesh_folder, ks, out, rebuild_mesh=True, concurrent=4, exp_csv=HEATING_CSV, timing=timing)
+    assert len(rows) == 64 and all(r["status"] == "success" for r in rows), [r["error"] for r in rows if r["error"]][:1]
+    assert [r["k"] for r in rows] == sorted(ks.tolist()) and timing["sessions"] == 4
+    assert all(np.isfinite(r["rmse"]) and 0.0 < r["rmse"] < 0.2 for r in rows)
+    coords, tris, tags = load_mesh_arrays(os.path.join(mesh_folder, "mesh.msh"))
+    mtags = yaml.safe_load(open(os.path.join(mesh_folder, "mesh_cfg.yaml")))["material_tags"]
+    assert 150_000 < len(coords) < 450_000                       # stock size (SURVEY 8a)
+    nodes = nearest_nodes(coords, list(watcher_points(cfg).values()))
+    finals = []
+    for k in (ks[0], ks[31], ks[63]):
+        c = copy.deepcopy(cfg)
+        c["mats"]["p_sample"]["k"] = float(k)
+        ref = ho.run_reference_algorithm(c, coords, tris, tags, mtags, HEATING_CSV, watcher_nodes=nodes)
+        got = np.genfromtxt(os.path.join(out, f"{k:.4f}", "watcher_points.csv"), delimiter=",", names=True)
+        assert len(got) == 100
+        assert np.abs(got["pside"] - ref["watchers"][:, 0]).max() <= 1e-4
+        assert np.abs(got["oside"] - ref["watchers"][:, 1]).max() <= 1e-4
+        finals.append(got["oside"][-1])
+    assert finals[0] < finals[1] < finals[2]                      # a better conductor heats the far side more
+    print(f"64 points x {len(coords)} DOF x 100 steps in {timing['points_s']:.2f} s of point loop "
+          f"({64 * len(coords) * 100 / timing['points_s']:.3e} DOF-updates/s)")

@@ -465,27 +465,6 @@ def test_two_contexts_on_two_threads_agree_with_sequential(hip, case_with_diamon
     assert np.array_equal(par["amg"], seq["amg"]) and np.array_equal(par["jac"], seq["jac"])   # deterministic reductions
 
 
-def test_graph_replay_gives_identical_results(hip, case_with_diamond_small, monkeypatch):
-    """HEATFLOW_GRAPH=1 replays the PCG loops from captured hipGraphs; the numbers must not change."""
-    cfg, stack, mesh = case_with_diamond_small
-    out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("HEATFLOW_GRAPH", flag)
-        for pc in (0, 1):
-            prob = make_problem(cfg, stack, mesh, precond=pc, assembly_mode=1)
-            try:
-                for bc in prob.bcs:
-                    bc.update(0.0)
-                for k in range(9):
-                    prob.step((k + 1) * prob.dt)
-                out[(flag, pc)] = (prob.state(), list(prob.iters))
-            finally:
-                prob.close()
-    for pc in (0, 1):
-        assert out[("0", pc)][1] == out[("1", pc)][1]
-        assert np.array_equal(out[("0", pc)][0], out[("1", pc)][0])
-
-
 def test_two_sided_heating_extension_matches_oracle(hip, tmp_path):
     """BASELINE config 4's "two-sided heating" has no reference implementation (cfgs/konopkova.yaml is a
     stub); the extension (second Gaussian line on the o-side coupler face, `oside` column) is checked
@@ -769,3 +748,78 @@ def test_two_heated_lines_take_two_response_directions(hip, case_no_diamond_smal
     assert out[0][2] == 0 and out[2][2] == 2
     assert np.abs(out[2][0] - out[0][0]).max() <= 2e-5
     assert out[2][1] < out[0][1]
+
+
+def test_golden_fixture_fields_are_reproduced_by_the_hip_path(hip):
+    """tests/golden/with_diamond_tiny.npz (mesh arrays, Dirichlet DOFs, 12 full fields; written by
+    tests/golden/make_golden.py from the oracle, which tests/test_oracle.py re-checks): the HIP path runs on
+    exactly those arrays and must give those fields to <= 1e-4 K at every step."""
+    from conftest import HEATING_CSV, load_cfg
+    from heatflow_amd.geometry import build_stack, scale_mesh_sizes
+    from heatflow_amd.bc import P1Space, RowDirichletBC
+    from heatflow_amd.heating import HeatingCurve
+    from heatflow_amd.solver import HeatProblem
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "with_diamond_tiny.npz"))
+    cfg = scale_mesh_sizes(load_cfg("geballe_with_diamond"), float(g["mesh_scale"]))
+    stack = build_stack(cfg)
+    mtags = {str(k): int(v) for k, v in zip(g["material_names"], g["material_tag_values"])}
+    ic = float(cfg["heating"]["ic_temp"])
+    heat = HeatingCurve(HEATING_CSV, ic, float(cfg["heating"]["fwhm"]))
+    V = P1Space(g["coords"])
+    bcs = [RowDirichletBC(V, "left", value=ic), RowDirichletBC(V, "right", value=ic), RowDirichletBC(V, "top", value=ic),
+           RowDirichletBC(V, "x", coord=stack.heated_z, length=abs(stack.r_sample) * 2, center=0.0, value=heat.gaussian)]
+    tk = {mtags[m.name]: m.properties["k"] for m in stack.materials}
+    trc = {mtags[m.name]: m.properties["rho_cv"] for m in stack.materials}
+    dt = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
+    for precond in (0, 1):
+        prob = HeatProblem(g["coords"], g["tris"], g["tags"], tk, trc, dt, bcs, ic, precond=precond)
+        try:
+            assert np.array_equal(prob.bc_dofs, g["bc_dofs"])                # the fixture's Dirichlet set
+            for b in prob.bcs:
+                b.update(0.0)
+            worst = 0.0
+            for k in range(g["fields"].shape[0]):
+                t = (k + 1) * prob.dt
+                assert t == pytest.approx(float(g["times"][k]), rel=0, abs=1e-20)
+                prob.step(t, only=[prob.bcs[3]])
+                worst = max(worst, float(np.abs(prob.state() - g["fields"][k]).max()))
+            assert worst <= FIELD_TOL_K, f"precond {precond}: worst |dT| = {worst:.3e} K"
+            assert g["fields"][-1].max() > 310.0
+        finally:
+            prob.close()
+
+
+def test_mesh_read_through_the_msh41_reader_runs_on_hip_and_matches_the_oracle(hip, tmp_path):
+    """A mesh in the reference's file format (MSH 4.1 ASCII, physical group per surface, tags that are not
+    list positions) goes read_msh -> reorder -> HIP; five steps past the onset of the heating against the
+    oracle on the same arrays."""
+    from conftest import HEATING_CSV, build_case
+    from heatflow_amd.mesh import load_mesh_arrays, write_msh41
+    from oracle import heat_oracle as ho
+
+    cfg, stack, mesh = build_case("geballe_no_diamond", 4.0)
+    perm = {int(t): 30 + 2 * int(t) for t in np.unique(mesh.tags)}
+    path = str(tmp_path / "mesh.msh")
+    write_msh41(path, mesh.coords, mesh.tris, np.array([perm[int(t)] for t in mesh.tags]),
+                {nm: perm[t] for nm, t in mesh.material_tags.items()}, surface_ids={v: k for k, v in perm.items()})
+    coords, tris, tags = load_mesh_arrays(path)                 # no npz sidecar: the 4.1 reader + Morton reorder
+    assert len(coords) == len(mesh.coords) and not np.array_equal(coords, mesh.coords)
+    mtags = {nm: perm[t] for nm, t in mesh.material_tags.items()}
+
+    class M:                                                    # what helpers.make_problem reads
+        pass
+    m = M()
+    m.coords, m.tris, m.tags, m.material_tags = coords, tris, tags, mtags
+    nsteps = 7                                                  # no-diamond dt = 1.875e-7: heating from step 2
+    ref = ho.run_reference_algorithm(cfg, coords, tris, tags, mtags, HEATING_CSV, num_steps=nsteps, keep_fields=True)
+    prob = make_problem(cfg, stack, m, precond=1)
+    try:
+        for b in prob.bcs:
+            b.update(0.0)
+        for k in range(nsteps):
+            prob.step((k + 1) * prob.dt, only=[prob.bcs[3]])
+            assert np.abs(prob.state() - ref["fields"][k]).max() <= FIELD_TOL_K
+        assert ref["fields"][-1].max() > 400.0 and max(prob.iters) >= 3
+    finally:
+        prob.close()

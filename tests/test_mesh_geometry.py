@@ -299,3 +299,32 @@ def test_native_and_numpy_quadtree_agree_on_the_reference_stacks(name, scale):
     a = Mesh("a", stack.bounds, stack.materials).build_mesh(use_native=True)
     b = Mesh("b", stack.bounds, stack.materials).build_mesh(use_native=False)
     assert np.array_equal(a.coords, b.coords) and np.array_equal(a.tris, b.tris) and np.array_equal(a.tags, b.tags)
+
+
+def _tri_key(coords, tris, tags):
+    """Triangles as sorted coordinate tuples + tag, in a canonical order (node numbering independent)."""
+    a = np.concatenate([np.sort(coords[tris].reshape(len(tris), -1), axis=1), np.asarray(tags, dtype=float)[:, None]], axis=1)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def test_msh41_writer_round_trip_keeps_physical_tags(tmp_path):
+    """MSH 4.1 as the reference's gmsh.write lays it out (one surface + one physical group per material,
+    mesh_and_materials/mesh.py:114-126, :191-195): written by write_msh41, read back by read_msh.  Surface
+    ids and physical tags are numbered differently on purpose: the cell tag must be the physical one."""
+    from heatflow_amd.mesh import write_msh41
+
+    cfg, stack, mesh = build_case("geballe_with_diamond", 16.0)
+    path = str(tmp_path / "m41.msh")
+    write_msh41(path, mesh.coords, mesh.tris, mesh.tags, mesh.material_tags,
+                surface_ids={int(t): 100 - int(t) for t in np.unique(mesh.tags)})
+    head = open(path).read(4000)
+    assert head.startswith("$MeshFormat\n4.1 0 8\n") and '2 4 "p_sample"' in head and "\n0 0 9 0\n" in head
+    coords, tris, tags = read_msh(path)
+    assert coords.shape == mesh.coords.shape and tris.shape == mesh.tris.shape
+    assert np.array_equal(_tri_key(coords, tris, tags), _tri_key(mesh.coords, mesh.tris, mesh.tags))   # bit-exact (%.17g)
+    # Mesh.write(version="4.1") goes the same way and keeps the npz sidecar
+    p2 = str(tmp_path / "mesh.msh")
+    mesh.write(p2, version="4.1")
+    c2, t2, g2 = read_msh(p2)
+    assert np.array_equal(_tri_key(c2, t2, g2), _tri_key(mesh.coords, mesh.tris, mesh.tags))
+    assert (tmp_path / "mesh.npz").is_file()
