@@ -15,6 +15,21 @@
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
+namespace {
+// coefficient tables of the row-gather kernel: indexed by position in the mesh's tag dictionary
+int upload_rg_tables(hf_ctx* ctx, const std::vector<double>& by_tag_k, const std::vector<double>* by_tag_c) {
+  if (!ctx->rg_ok) return HF_OK;
+  std::vector<double> k(64, 0.0), c(64, 0.0);
+  for (size_t q = 0; q < ctx->h_rg_tags.size(); ++q) {
+    k[q] = by_tag_k[ctx->h_rg_tags[q]];
+    if (by_tag_c) c[q] = (*by_tag_c)[ctx->h_rg_tags[q]];
+  }
+  HF_HIP(copy_sync(ctx, ctx->d_kappa_rg, k.data(), sizeof(double) * 64, hipMemcpyHostToDevice));
+  if (by_tag_c) HF_HIP(copy_sync(ctx, ctx->d_rhoc_rg, c.data(), sizeof(double) * 64, hipMemcpyHostToDevice));
+  return HF_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char* hf_version(void) { return "heatflow_hip 0.1 (gfx950)"; }
@@ -56,7 +71,7 @@ int hf_destroy(hf_ctx* ctx) {
   (void)hipSetDevice(ctx->dev);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   dev_free(&ctx->d_zr); dev_free(&ctx->d_elem); dev_free(&ctx->d_kappa); dev_free(&ctx->d_rhoc);
-  dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_cdict_ptr); dev_free(&ctx->d_cdict); dev_free(&ctx->d_cid); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
+  dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_cdict_ptr); dev_free(&ctx->d_cdict); dev_free(&ctx->d_cid); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent); dev_free(&ctx->d_rg_hdr); dev_free(&ctx->d_rg_ell); dev_free(&ctx->d_rg_cid); dev_free(&ctx->d_rg_zrb); dev_free(&ctx->d_kappa_rg); dev_free(&ctx->d_rhoc_rg); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
   dev_free(&ctx->d_bc_dofs); dev_free(&ctx->d_g); dev_free(&ctx->d_lift_rows); dev_free(&ctx->d_lift_ptr);
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_uprev); dev_free(&ctx->d_ustart);
@@ -102,28 +117,12 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   for (int c = 0; c < ctx->nchunks_s; ++c)
     ctx->max_chunk_nnz_s = std::max(ctx->max_chunk_nnz_s, P.rowptr[std::min<int64_t>(n, (c + 1LL) * TS)] - P.rowptr[c * TS]);
   // compressed columns per SpMV chunk: sorted unique columns + 16-bit position per nonzero
-  std::vector<int32_t> cdict_ptr(ctx->nchunks_s + 1, 0), cdict;
-  std::vector<uint16_t> cid(P.colidx.size());
-  {
-    std::vector<int32_t> seen(n, -1), lid(n, 0), list;
-    cdict.reserve(static_cast<size_t>(n) + n / 2);
-    ctx->max_cdict = 0;
-    for (int c = 0; c < ctx->nchunks_s; ++c) {
-      const int64_t k0 = P.rowptr[c * TS], k1 = P.rowptr[std::min<int64_t>(n, (c + 1LL) * TS)];
-      list.clear();
-      for (int64_t k = k0; k < k1; ++k) {
-        const int32_t col = P.colidx[k];
-        if (seen[col] != c) { seen[col] = c; list.push_back(col); }
-      }
-      std::sort(list.begin(), list.end());
-      if (list.size() > 65535) return fail(ctx, HF_ERR_ARG, "SpMV chunk %d touches %zu columns (16-bit positions)", c, list.size());
-      for (size_t q = 0; q < list.size(); ++q) lid[list[q]] = static_cast<int32_t>(q);
-      for (int64_t k = k0; k < k1; ++k) cid[k] = static_cast<uint16_t>(lid[P.colidx[k]]);
-      cdict.insert(cdict.end(), list.begin(), list.end());
-      cdict_ptr[c + 1] = static_cast<int32_t>(cdict.size());
-      ctx->max_cdict = std::max(ctx->max_cdict, static_cast<int>(list.size()));
-    }
-  }
+  ColDict sd;
+  if (!build_coldict(P.rowptr, P.colidx, n, TS, sd)) return fail(ctx, HF_ERR_ARG, "an SpMV chunk touches more than 65535 columns (16-bit positions)");
+  std::vector<int32_t>& cdict_ptr = sd.ptr;
+  std::vector<int32_t>& cdict = sd.dict;
+  std::vector<uint16_t>& cid = sd.id;
+  ctx->max_cdict = sd.max_dict;
   if (const char* e = std::getenv("HEATFLOW_SPMV_C16")) ctx->c16 = (e[0] != '0');
   if (static_cast<size_t>(ctx->max_chunk_nnz_s + ctx->max_cdict) * 8 > 64 * 1024) ctx->c16 = false;   // LDS window of the kernel
   ctx->max_blk_nnz = P.max_blk_nnz;
@@ -150,6 +149,23 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_eptr, P.blk_eptr.size()));
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_cptr, P.blk_cptr.size()));
   HF_TRY(dev_alloc(ctx, &ctx->d_blk_ent, P.blk_ent.size()));
+  ctx->rg_ok = P.rg.ok && rowgather_smem_bytes(P.max_blk_nnz, P.rg.cols.max_dict) <= 160 * 1024;
+  ctx->rg_grid = 0;
+  if (ctx->rg_ok) {
+    const RowGather& G = P.rg;
+    ctx->rg_max_dict = G.cols.max_dict;
+    ctx->h_rg_tags = G.tags;
+    HF_TRY(dev_alloc(ctx, &ctx->d_rg_hdr, G.hdr.size()));
+    HF_TRY(dev_alloc(ctx, &ctx->d_rg_ell, G.ell.size()));
+    HF_TRY(dev_alloc(ctx, &ctx->d_rg_cid, G.cols.id.size() + 16));          // read in 16-byte vectors from an 8-aligned start
+    HF_TRY(dev_alloc(ctx, &ctx->d_rg_zrb, G.cols.dict.size()));
+    HF_TRY(dev_alloc(ctx, &ctx->d_kappa_rg, 64));
+    HF_TRY(dev_alloc(ctx, &ctx->d_rhoc_rg, 64));
+    HF_HIP(copy_sync(ctx, ctx->d_rg_hdr, G.hdr.data(), sizeof(int4) * G.hdr.size(), hipMemcpyHostToDevice));
+    HF_HIP(copy_sync(ctx, ctx->d_rg_ell, G.ell.data(), sizeof(uint16_t) * G.ell.size(), hipMemcpyHostToDevice));
+    HF_HIP(hipMemsetAsync(ctx->d_rg_cid + G.cols.id.size(), 0, sizeof(uint16_t) * 16, ctx->stream));
+    HF_HIP(copy_sync(ctx, ctx->d_rg_cid, G.cols.id.data(), sizeof(uint16_t) * G.cols.id.size(), hipMemcpyHostToDevice));
+  }
   HF_TRY(dev_alloc(ctx, &ctx->d_M, ctx->nnz));
   HF_TRY(dev_alloc(ctx, &ctx->d_A, ctx->nnz));
   HF_TRY(dev_alloc(ctx, &ctx->d_dinv, n));
@@ -167,6 +183,17 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   HF_TRY(dev_alloc(ctx, &ctx->d_z2, n));
   free_amg(ctx);
   HF_HIP(copy_sync(ctx, ctx->d_zr, zr, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+  if (ctx->rg_ok) {   // per-block copies of the column lists' coordinates, gathered on the device
+    const std::vector<int32_t>& dict = P.rg.cols.dict;
+    DevTemp<int32_t> t_dict;
+    HF_TRY(dev_alloc(ctx, &t_dict.p, dict.size()));
+    HF_HIP(copy_sync(ctx, t_dict.p, dict.data(), sizeof(int32_t) * dict.size(), hipMemcpyHostToDevice));
+    const int64_t total = static_cast<int64_t>(dict.size());
+    hipLaunchKernelGGL(k_gather_coords, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, ctx->stream, total, t_dict.p,
+                       ctx->d_zr, ctx->d_rg_zrb);
+    HF_HIP(hipGetLastError());
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+  }
   HF_HIP(copy_sync(ctx, ctx->d_elem, elem.data(), sizeof(int4) * ne, hipMemcpyHostToDevice));
   HF_HIP(copy_sync(ctx, ctx->d_rowptr, P.rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
   HF_HIP(copy_sync(ctx, ctx->d_colidx, P.colidx.data(), sizeof(int32_t) * ctx->nnz, hipMemcpyHostToDevice));
@@ -204,6 +231,7 @@ int hf_set_materials(hf_ctx* ctx, int32_t n_mat, const int32_t* tags, const doub
     if (ctx->h_tag_used[t] && std::isnan(tk[t])) return fail(ctx, HF_ERR_ARG, "hf_set_materials: cell tag %d has no material", t);
   HF_HIP(copy_sync(ctx, ctx->d_kappa, tk.data(), sizeof(double) * ctx->tab_len, hipMemcpyHostToDevice));
   HF_HIP(copy_sync(ctx, ctx->d_rhoc, tc.data(), sizeof(double) * ctx->tab_len, hipMemcpyHostToDevice));
+  HF_TRY(upload_rg_tables(ctx, tk, &tc));
   ctx->have_mat = true;
   ctx->assembled = false;
   return HF_OK;
@@ -223,6 +251,7 @@ int hf_update_kappa(hf_ctx* ctx, int32_t n_mat, const int32_t* tags, const doubl
     tk[tags[i]] = kappa[i];
   }
   HF_HIP(copy_sync(ctx, ctx->d_kappa, tk.data(), sizeof(double) * ctx->tab_len, hipMemcpyHostToDevice));
+  HF_TRY(upload_rg_tables(ctx, tk, nullptr));
   return hf_assemble(ctx, ctx->dt, ctx->mode);
 }
 
@@ -252,7 +281,7 @@ int hf_assemble(hf_ctx* ctx, double dt, int32_t mode) {
   if (!ctx) return HF_ERR_ARG;
   if (!ctx->have_mesh || !ctx->have_mat) return fail(ctx, HF_ERR_STATE, "hf_assemble needs hf_set_mesh and hf_set_materials first");
   if (!(dt > 0.0)) return fail(ctx, HF_ERR_ARG, "hf_assemble: dt must be positive");
-  if (mode < 0 || mode > 2) return fail(ctx, HF_ERR_ARG, "hf_assemble: unknown mode %d", mode);
+  if (mode < 0 || mode > 3) return fail(ctx, HF_ERR_ARG, "hf_assemble: unknown mode %d", mode);
   HF_HIP(hipSetDevice(ctx->dev));
   ctx->dt = dt;
   ctx->mode = mode;

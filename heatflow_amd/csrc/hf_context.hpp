@@ -86,6 +86,14 @@ struct hf_ctx {
   int nblk_a = 0;
   int max_blk_nnz = 0, ncolors = 0;
   int64_t elist_len = 0;
+  // device: row-gather assembly lists (RowGather in hf_pattern.hpp) and coefficient tables by tag-dictionary index
+  bool rg_ok = false;
+  int4* d_rg_hdr = nullptr;
+  uint16_t *d_rg_ell = nullptr, *d_rg_cid = nullptr;
+  double2* d_rg_zrb = nullptr;      // coordinates of every block's column list (own rows + halo)
+  int rg_max_dict = 0, rg_grid = 0;
+  std::vector<int32_t> h_rg_tags;
+  double *d_kappa_rg = nullptr, *d_rhoc_rg = nullptr;
   // device: matrices
   double *d_M = nullptr, *d_A = nullptr, *d_dinv = nullptr;
   // device: Dirichlet

@@ -213,6 +213,158 @@ __global__ __launch_bounds__(RBA) void k_assemble_lds(int n, int cap, const int3
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Assembly, row gather (HF_ASM_ROW_GATHER): lane t of a workgroup owns CSR row r0 + t and visits the
+// triangles at its node one after another (ELL slab of 16-bit entries, hf_pattern.hpp RowGather).  A
+// triangle is described by the positions of its two other vertices inside the row's column list, so a
+// contribution's slot is known without any search or offset table, and the element array is never read.
+// Per block of RBA rows the kernel stages, all as coalesced 16-byte streams: the rows' 16-bit column
+// positions, the coordinates of the block's column list (own rows + halo, a per-block copy made at
+// hf_set_mesh) and its ELL entries; the (M, A) value slab lives in LDS and is streamed out once.  The
+// visit loop touches LDS only.  Rows are private to their lane: no atomics, no colours, no barriers
+// inside the loop, and the order of additions is the list order - bitwise reproducible.
+// Workgroups are persistent: while block b is computed the loads of the workgroup's next block are in
+// flight into registers and the stores of its previous block drain, so the three phases overlap.
+// Every triangle is evaluated once per vertex ("me", next, previous in the triangle's own cyclic
+// order).  The formulas are symmetric by construction, so the three evaluations agree bit for bit
+// where they must (A_ij == A_ji) without agreeing on a vertex order:
+//   edges   e_v = P_next(v) - P_prev(v): the same subtraction from every vertex's point of view
+//   K_ab  = ks * (e_a . e_b)             (products commute)
+//   d     = max |e_a x e_b| over the three edge pairs (three roundings of twice the area)
+//   rsum  = (lo + mid) + hi of the three radii sorted by value
+//   M_aa  = ms/30 * (2 r_a + rsum),  M_ab = ms/60 * (rsum + (r_a + r_b))
+// One IEEE division per evaluation (1/d^2); constant divisors are multiplications by rounded reciprocals.
+// ------------------------------------------------------------------------------------------
+struct ElemRow { double m0, m1, m2, k0, k1, k2; };   // row "me" of the element matrices: (me,me) (me,next) (me,prev)
+
+__device__ __forceinline__ ElemRow element_row(const double2 Pi, const double2 Pj, const double2 Pk, double rho_c, double kappa) {
+#pragma clang fp contract(off)
+  const double eix = Pk.x - Pj.x, eiy = Pk.y - Pj.y;     // edge opposite "me"
+  const double ejx = Pi.x - Pk.x, ejy = Pi.y - Pk.y;     // opposite next
+  const double ekx = Pj.x - Pi.x, eky = Pj.y - Pi.y;     // opposite previous
+  const double c1 = fabs(ejx * eky - ejy * ekx), c2 = fabs(ekx * eiy - eky * eix), c3 = fabs(eix * ejy - eiy * ejx);
+  const double d = fmax(fmax(c1, c2), c3);
+  const double ab_lo = fmin(Pi.y, Pj.y), ab_hi = fmax(Pi.y, Pj.y);
+  const double lo = fmin(ab_lo, Pk.y), hi = fmax(ab_hi, Pk.y), mid = fmax(ab_lo, fmin(ab_hi, Pk.y));
+  const double rsum = (lo + mid) + hi;
+  const double area = 0.5 * d;
+  const double ks = kappa * area * (rsum * (1.0 / 3.0)) * (1.0 / (d * d));
+  const double ms30 = rho_c * area * (1.0 / 30.0), ms60 = rho_c * area * (1.0 / 60.0);
+  ElemRow o;
+  o.k0 = ks * (eix * eix + eiy * eiy);
+  o.k1 = ks * (eix * ejx + eiy * ejy);
+  o.k2 = ks * (eix * ekx + eiy * eky);
+  o.m0 = ms30 * (2.0 * Pi.y + rsum);
+  o.m1 = ms60 * (rsum + (Pi.y + Pj.y));
+  o.m2 = ms60 * (rsum + (Pi.y + Pk.y));
+  return o;
+}
+
+constexpr int RG_NC = 4;   // 16-byte vectors of column positions a lane can prefetch (RBA * 8 * RG_NC >= slab slots: rows hold <= 32 entries)
+constexpr int RG_NX = 5;   // coordinate pairs a lane can prefetch (RBA * RG_NX >= column-list length, checked on the host)
+
+__global__ __launch_bounds__(RBA) void k_assemble_rows(int nblk, int cap /* slab slots, even */, int capd /* column-list slots */,
+                                                       const int32_t* __restrict__ rowptr,
+                                                       const int4* __restrict__ hdr /* 2 per block */,
+                                                       const uint4* __restrict__ ell, const uint4* __restrict__ cid16,
+                                                       const double2* __restrict__ zrb,
+                                                       const double* __restrict__ kappa_idx, const double* __restrict__ rhoc_idx,
+                                                       double dt, double* __restrict__ Mv, double* __restrict__ Av) {
+  extern __shared__ double smem[];
+  double2* sMA = reinterpret_cast<double2*>(smem);                   // (M, A) per slot
+  double2* sXd = sMA + cap;                                          // coordinates of the block's column list
+  int* sR = reinterpret_cast<int*>(sXd + capd);                      // row starts inside the slab
+  uint4* sC4 = reinterpret_cast<uint4*>(sR + RBA + 4);               // column-list position per slot, from the 8-aligned start
+  const uint16_t* sC = reinterpret_cast<const uint16_t*>(sC4);
+
+  const int t = threadIdx.x;
+  for (int k = t; k < cap; k += RBA) sMA[k] = make_double2(0.0, 0.0);
+
+  // prefetch registers of the next block
+  int4 hA, hB;
+  uint4 pe, pc[RG_NC];
+  double2 px[RG_NX];
+  int pr = 0;
+  auto prefetch = [&](int blk) {
+    hA = hdr[2 * blk];                                               // (k0, nk, d0, nd)
+    hB = hdr[2 * blk + 1];                                           // (ell offset in 16-byte units, groups of 8 visits, local id of row r0, rows)
+    pe = ell[hB.x + t];
+    const int c0 = hA.x >> 3, nc = ((hA.x + hA.y + 7) >> 3) - c0;
+#pragma unroll
+    for (int u = 0; u < RG_NC; ++u) pc[u] = (t + u * RBA < nc) ? cid16[c0 + t + u * RBA] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < RG_NX; ++u) px[u] = (t + u * RBA < hA.w) ? zrb[hA.z + t + u * RBA] : make_double2(0.0, 0.0);
+    pr = (t < hB.w) ? rowptr[blk * RBA + t] - hA.x : 0;
+  };
+  int blk = blockIdx.x;
+  if (blk < nblk) prefetch(blk);
+  while (blk < nblk) {
+    // stage the prefetched block
+    const int4 cA = hA, cB = hB;
+    const uint4 ce = pe;
+    const int nc = ((cA.x + cA.y + 7) >> 3) - (cA.x >> 3);
+#pragma unroll
+    for (int u = 0; u < RG_NC; ++u) if (t + u * RBA < nc) sC4[t + u * RBA] = pc[u];
+#pragma unroll
+    for (int u = 0; u < RG_NX; ++u) if (t + u * RBA < cA.w) sXd[t + u * RBA] = px[u];
+    sR[t] = pr;
+    __syncthreads();
+    const int nxt = blk + gridDim.x;
+    if (nxt < nblk) prefetch(nxt);                                   // in flight during the visit loop
+
+    if (t < cB.w) {
+      const int base = sR[t];
+      const int sbase = base + (cA.x & 7);                           // the position array starts at the 8-aligned slot
+      const int ci = cB.z + t;                                       // my own position in the column list
+      const double2 Pi = sXd[ci];
+      double dM = 0.0, dA = 0.0;
+      int pd = 0;                                                    // diagonal: the slot whose column is my own row
+      while (pd < 31 && sC[sbase + pd] < ci) ++pd;
+      for (int g = 0; g < cB.y; ++g) {
+        const uint4 ev = g == 0 ? ce : ell[cB.x + g * RBA + t];
+        const unsigned w[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const unsigned e = (w[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu;
+          if (e == 0xFFFFu) continue;
+          const int pj = e & 31u, pk = (e >> 5) & 31u, tg = e >> 10;
+          const double2 Pj = sXd[sC[sbase + pj]], Pk = sXd[sC[sbase + pk]];
+          const ElemRow r = element_row(Pi, Pj, Pk, rhoc_idx[tg], kappa_idx[tg]);
+          dM += r.m0;
+          dA += fma(dt, r.k0, r.m0);
+          double2 v = sMA[base + pj];
+          v.x += r.m1;
+          v.y += fma(dt, r.k1, r.m1);
+          sMA[base + pj] = v;
+          v = sMA[base + pk];
+          v.x += r.m2;
+          v.y += fma(dt, r.k2, r.m2);
+          sMA[base + pk] = v;
+        }
+      }
+      sMA[base + pd] = make_double2(dM, dA);
+    }
+    __syncthreads();
+    // stream the slab out and leave it zeroed for the next block (slot k stays with the lane that reads it here)
+    for (int k = t; k < cA.y; k += RBA) {
+      const double2 v = sMA[k];
+      Mv[cA.x + k] = v.x;
+      Av[cA.x + k] = v.y;
+      sMA[k] = make_double2(0.0, 0.0);
+    }
+    blk = nxt;
+    // no barrier needed here: the staging stores above touch sC / sXd / sR only after every lane has passed the
+    // barrier that ended the visit loop, and the slab is re-read only behind the next staging barrier
+  }
+}
+
+// per-block copy of the coordinates of each block's column list (hf_set_mesh, once)
+__global__ void k_gather_coords(int64_t total, const int32_t* __restrict__ dict, const double2* __restrict__ zr,
+                                double2* __restrict__ zrb) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < total) zrb[i] = zr[dict[i]];
+}
+
 // Baseline: one thread per element, f64 atomics into global CSR (values must be zeroed).
 __global__ __launch_bounds__(TPB) void k_assemble_global(int ne, const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ colidx,

@@ -7,11 +7,115 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // host side: sparsity pattern, owner lists, colouring
 // ------------------------------------------------------------------------------------------
+// Per-chunk compressed columns: the sorted list of the columns a chunk of consecutive rows touches (its own rows
+// plus a halo, ~1.3 entries per row) and a 16-bit position in that list per nonzero.
+struct ColDict {
+  std::vector<int32_t> ptr, dict;
+  std::vector<uint16_t> id;
+  int max_dict = 0;
+};
+
+// Row-gather assembly lists (k_assemble_rows): per block of RBA rows an ELL slab of 16-bit entries in groups of
+// eight visits, laid out [group][lane][8] so that a lane reads its eight entries with one 16-byte load and a
+// wavefront reads 1 KB contiguously.  Entry q of lane t describes the q-th triangle at node r0 + t by the
+// positions of its next and previous vertex (in the triangle's own cyclic order) inside row t's sorted column
+// list (5 bits each) and the index of its cell tag in the mesh's tag dictionary (6 bits); 0xFFFF pads.
+// `hdr` holds two int4 per block: (k0, nk, d0, nd) = the block's slice of the CSR arrays and of the column
+// lists, and (ELL offset in 16-byte units, groups, position of row r0 in the block's column list, rows).
+struct RowGather {
+  bool ok = false;
+  std::vector<int4> hdr;
+  std::vector<uint16_t> ell;
+  std::vector<int32_t> tags;       // tag dictionary: dictionary index -> cell tag
+  ColDict cols;                    // column lists per RBA-row block
+};
+
 struct Pattern {
   std::vector<int32_t> rowptr, colidx, blk_eptr, blk_cptr, blk_elist;
   std::vector<int2> blk_ent;       // 3 x int2 per list entry: element record + nine slot offsets + ownership mask
   int max_blk_nnz = 0, ncolors = 0;
+  RowGather rg;
 };
+
+// false when a chunk touches more than 65535 columns (16-bit positions)
+bool build_coldict(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int32_t n, int rows, ColDict& D) {
+  const int nchunk = (n + rows - 1) / rows;
+  D.ptr.assign(static_cast<size_t>(nchunk) + 1, 0);
+  D.dict.clear();
+  D.dict.reserve(static_cast<size_t>(n) + n / 2);
+  D.id.resize(colidx.size());
+  D.max_dict = 0;
+  std::vector<int32_t> seen(n, -1), lid(n, 0), list;
+  for (int c = 0; c < nchunk; ++c) {
+    const int64_t k0 = rowptr[static_cast<size_t>(c) * rows], k1 = rowptr[std::min<int64_t>(n, (c + 1LL) * rows)];
+    list.clear();
+    for (int64_t k = k0; k < k1; ++k) {
+      const int32_t col = colidx[k];
+      if (seen[col] != c) { seen[col] = c; list.push_back(col); }
+    }
+    std::sort(list.begin(), list.end());
+    if (list.size() > 65535) return false;
+    for (size_t q = 0; q < list.size(); ++q) lid[list[q]] = static_cast<int32_t>(q);
+    for (int64_t k = k0; k < k1; ++k) D.id[k] = static_cast<uint16_t>(lid[colidx[k]]);
+    D.dict.insert(D.dict.end(), list.begin(), list.end());
+    D.ptr[c + 1] = static_cast<int32_t>(D.dict.size());
+    D.max_dict = std::max(D.max_dict, static_cast<int>(list.size()));
+  }
+  return true;
+}
+
+// Row-gather lists from the node -> element adjacency (nptr / nlist, elements in ascending order per node).
+// Not available (rg.ok = false; the LDS scatter kernels are used instead) when a row holds more than 32 entries,
+// the mesh carries more than 64 distinct cell tags or a block's column list is longer than the kernel prefetches.
+void build_rowgather(int32_t n, int32_t ne, const int32_t* tri, const int32_t* tag, const std::vector<int32_t>& nptr,
+                     const std::vector<int32_t>& nlist, Pattern& P) {
+  RowGather& G = P.rg;
+  G.ok = false;
+  for (int32_t i = 0; i < n; ++i)
+    if (P.rowptr[i + 1] - P.rowptr[i] > 32) return;
+  {
+    std::vector<int32_t> t(tag, tag + ne);
+    std::sort(t.begin(), t.end());
+    t.erase(std::unique(t.begin(), t.end()), t.end());
+    if (t.size() > 64) return;
+    G.tags = t;
+  }
+  if (!build_coldict(P.rowptr, P.colidx, n, RBA, G.cols)) return;
+  if (G.cols.max_dict > RBA * RG_NX || P.max_blk_nnz + 8 > 8 * RBA * RG_NC) return;
+  const int nblk = (n + RBA - 1) / RBA;
+  G.hdr.resize(2 * static_cast<size_t>(nblk));
+  G.ell.clear();
+  G.ell.reserve(static_cast<size_t>(8) * n + 8 * RBA);
+  for (int b = 0; b < nblk; ++b) {
+    const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
+    int w = 0;
+    for (int32_t i = r0; i < r1; ++i) w = std::max(w, nptr[i + 1] - nptr[i]);
+    const int groups = std::max(1, (w + 7) / 8);
+    const size_t off = G.ell.size();
+    if (off / 8 > static_cast<size_t>(INT32_MAX)) return;
+    G.ell.resize(off + static_cast<size_t>(groups) * RBA * 8, static_cast<uint16_t>(0xFFFF));
+    const int32_t* dict = &G.cols.dict[G.cols.ptr[b]];
+    const int32_t* dend = &G.cols.dict[G.cols.ptr[b + 1]];
+    G.hdr[2 * b] = make_int4(P.rowptr[r0], P.rowptr[r1] - P.rowptr[r0], G.cols.ptr[b], G.cols.ptr[b + 1] - G.cols.ptr[b]);
+    G.hdr[2 * b + 1] = make_int4(static_cast<int>(off / 8), groups, static_cast<int>(std::lower_bound(dict, dend, r0) - dict), r1 - r0);
+    for (int32_t i = r0; i < r1; ++i) {
+      const int32_t* rb = &P.colidx[P.rowptr[i]];
+      const int32_t* re = &P.colidx[P.rowptr[i + 1]];
+      const int t = i - r0;
+      for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
+        const int32_t e = nlist[q];
+        int a = 0;
+        while (tri[3 * e + a] != i) ++a;
+        const uint32_t pj = static_cast<uint32_t>(std::lower_bound(rb, re, tri[3 * e + (a + 1) % 3]) - rb);
+        const uint32_t pk = static_cast<uint32_t>(std::lower_bound(rb, re, tri[3 * e + (a + 2) % 3]) - rb);
+        const uint32_t tg = static_cast<uint32_t>(std::lower_bound(G.tags.begin(), G.tags.end(), tag[e]) - G.tags.begin());
+        const int v = q - nptr[i];
+        G.ell[off + (static_cast<size_t>(v >> 3) * RBA + t) * 8 + (v & 7)] = static_cast<uint16_t>(pj | (pk << 5) | (tg << 10));
+      }
+    }
+  }
+  G.ok = true;
+}
 
 int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const int32_t* tag, Pattern& P) {
   std::vector<int32_t> nptr(static_cast<size_t>(n) + 1, 0);
@@ -115,6 +219,7 @@ int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const 
                                        static_cast<int>(pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24)));
     }
   }
+  build_rowgather(n, ne, tri, tag, nptr, nlist, P);
   return HF_OK;
 }
 
@@ -141,7 +246,37 @@ int launch_assemble_lds(hf_ctx* ctx, bool colored, const double* kappa_tab, cons
   return HF_OK;
 }
 
+size_t rowgather_smem_bytes(int max_blk_nnz, int max_dict) {
+  const size_t cap = static_cast<size_t>((max_blk_nnz + 1) & ~1);
+  return cap * 16 + static_cast<size_t>(max_dict) * 16 + (RBA + 4) * 4 + (cap / 8 + 3) * 16;
+}
+
+// Row-gather element kernel into (Mout, Aout); coefficient tables indexed by the tag dictionary.
+int launch_assemble_rows(hf_ctx* ctx, const double* kappa_idx, const double* rhoc_idx, double dt, double* Mout, double* Aout) {
+  const int cap = (ctx->max_blk_nnz + 1) & ~1;
+  const int capd = ctx->rg_max_dict;
+  const size_t sm = rowgather_smem_bytes(ctx->max_blk_nnz, capd);
+  if (ctx->rg_grid == 0) {   // persistent workgroups: as many as fit the chip at this LDS footprint
+    if (sm > 64 * 1024)
+      HF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 static_cast<int>(sm)));
+    int per_cu = 0, ncu = 0;
+    HF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_assemble_rows), RBA, sm));
+    HF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->dev));
+    ctx->rg_grid = std::max(1, std::min(ctx->nblk_a, std::max(1, per_cu) * std::max(1, ncu)));
+  }
+  hipLaunchKernelGGL(k_assemble_rows, dim3(ctx->rg_grid), dim3(RBA), sm, ctx->stream, ctx->nblk_a, cap, capd, ctx->d_rowptr,
+                     ctx->d_rg_hdr, reinterpret_cast<const uint4*>(ctx->d_rg_ell), reinterpret_cast<const uint4*>(ctx->d_rg_cid),
+                     ctx->d_rg_zrb, kappa_idx, rhoc_idx, dt, Mout, Aout);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
 int launch_assemble(hf_ctx* ctx) {
+  if (ctx->mode == HF_ASM_ROW_GATHER && ctx->rg_ok)
+    return launch_assemble_rows(ctx, ctx->d_kappa_rg, ctx->d_rhoc_rg, ctx->dt, ctx->d_M, ctx->d_A);
+  if (ctx->mode == HF_ASM_ROW_GATHER)   // lists not available for this mesh (row > 32 entries or > 64 cell tags): deterministic LDS variant
+    return launch_assemble_lds(ctx, true, ctx->d_kappa, ctx->d_rhoc, ctx->dt, ctx->d_M, ctx->d_A);
   if (ctx->mode == HF_ASM_LDS_COLORED || ctx->mode == HF_ASM_LDS_ATOMIC) {
     return launch_assemble_lds(ctx, ctx->mode == HF_ASM_LDS_COLORED, ctx->d_kappa, ctx->d_rhoc, ctx->dt, ctx->d_M, ctx->d_A);
   } else {

@@ -123,7 +123,7 @@ class SimulationSession:
     """
 
     def __init__(self, coords, tris, tags, material_tags, *, device_id=0, backend=None, rtol=DEFAULT_RTOL,
-                 max_it=DEFAULT_MAX_IT, assembly_mode=1, precond=1):
+                 max_it=DEFAULT_MAX_IT, assembly_mode=3, precond=1):
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.tris = np.ascontiguousarray(tris, dtype=np.int32)
         self.tags = np.ascontiguousarray(tags, dtype=np.int32)

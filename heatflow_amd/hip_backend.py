@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HEATFLOW_HIP_LIB") or os.path.join(_HERE, "csrc", "libheatflow_hip.so")  # env: A/B builds
 
 HF_OK, HF_ERR_ARG, HF_ERR_STATE, HF_ERR_HIP, HF_ERR_NOCONV, HF_ERR_ALLOC = 0, -1, -2, -3, -4, -5
-ASM_LDS_ATOMIC, ASM_LDS_COLORED, ASM_GLOBAL_ATOMIC = 0, 1, 2
+ASM_LDS_ATOMIC, ASM_LDS_COLORED, ASM_GLOBAL_ATOMIC, ASM_ROW_GATHER = 0, 1, 2, 3
 PC_JACOBI, PC_AMG = 0, 1
 K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS, K_STREAM_READ = range(7)
 

@@ -17,7 +17,7 @@ import numpy as np
 from scipy.spatial import cKDTree
 
 from .bc import gather_bc_values, merge_bcs
-from .hip_backend import ASM_LDS_COLORED, PC_AMG, PC_JACOBI, HeatflowHIP
+from .hip_backend import ASM_ROW_GATHER, PC_AMG, PC_JACOBI, HeatflowHIP
 
 # Default PCG tolerance: at rtol = 1e-10 the temperature field agrees with a sparse
 # direct solve of the same system to ~3e-6 K (measured on the stock and the 1M-DOF
@@ -37,14 +37,15 @@ class HeatProblem:
     bcs : list of RowDirichletBC in application order (later wins on shared DOFs)
     u0 : scalar or (n,) initial temperature
     backend : an object with the HeatflowHIP interface; default = a new HeatflowHIP
-    assembly_mode : ASM_LDS_COLORED (default: bitwise reproducible matrices, 80 us at 1M DOF) or
-              ASM_LDS_ATOMIC (LDS atomics, 50 us, diagonals summed in arrival order) / ASM_GLOBAL_ATOMIC
+    assembly_mode : ASM_ROW_GATHER (default: a lane per CSR row, no atomics, bitwise reproducible matrices),
+              ASM_LDS_COLORED (LDS scatter by colours, reproducible), ASM_LDS_ATOMIC (LDS atomics, diagonals
+              summed in arrival order) or ASM_GLOBAL_ATOMIC (baseline)
     precond : PC_JACOBI (Jacobi-PCG, the north-star solver) or PC_AMG (PCG preconditioned by a
               smoothed-aggregation V-cycle: same stopping rule and answer, ~50x fewer iterations)
     """
 
     def __init__(self, coords, tris, tags, tag_to_k, tag_to_rho_cv, dt, bcs, u0, *, backend=None, device_id=0,
-                 assembly_mode=ASM_LDS_COLORED, rtol=DEFAULT_RTOL, atol=0.0, max_it=DEFAULT_MAX_IT,
+                 assembly_mode=ASM_ROW_GATHER, rtol=DEFAULT_RTOL, atol=0.0, max_it=DEFAULT_MAX_IT,
                  precond=PC_JACOBI, amg_reuse=False):
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.n = self.coords.shape[0]

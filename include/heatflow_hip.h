@@ -54,12 +54,19 @@ enum {
 /* Assembly variants (all are per-element kernels, results agree to rounding):
  *   HF_ASM_LDS_ATOMIC    a workgroup owns 256 CSR rows, stages their value slab in LDS,
  *                        scatter-adds the incident elements with LDS f64 atomics and
- *                        streams the slab out once (coalesced).  Default.
+ *                        streams the slab out once (coalesced).
  *   HF_ASM_LDS_COLORED   same staging, elements processed colour by colour with plain
  *                        LDS read-modify-write: bitwise reproducible.
  *   HF_ASM_GLOBAL_ATOMIC one thread per element, f64 atomics straight into global CSR
- *                        (baseline / cross-check). */
-enum { HF_ASM_LDS_ATOMIC = 0, HF_ASM_LDS_COLORED = 1, HF_ASM_GLOBAL_ATOMIC = 2 };
+ *                        (baseline / cross-check).
+ *   HF_ASM_ROW_GATHER    a lane owns one CSR row and visits the triangles at its node (16-bit
+ *                        list entries = positions of the two other vertices in the row); the
+ *                        slab, the column positions and the coordinates of the block live in
+ *                        LDS, every global access is a coalesced stream; no atomics, no
+ *                        colours, bitwise reproducible.  Default of the entry points.  Falls
+ *                        back to HF_ASM_LDS_COLORED for meshes with a row of more than 32
+ *                        entries or more than 64 distinct cell tags. */
+enum { HF_ASM_LDS_ATOMIC = 0, HF_ASM_LDS_COLORED = 1, HF_ASM_GLOBAL_ATOMIC = 2, HF_ASM_ROW_GATHER = 3 };
 
 /* Kernels addressable by hf_time_kernel */
 enum {

@@ -24,7 +24,7 @@ def _rel_row_err(dev, ref, rowptr):
     return np.max(np.abs(dev - ref) / scale[rows])
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", ["with_diamond", "no_diamond"])
 def test_assembly_matches_oracle(hip, case, mode, case_with_diamond_small, case_no_diamond_small):
     from oracle import heat_oracle as ho
@@ -52,7 +52,8 @@ def test_assembly_matches_oracle(hip, case, mode, case_with_diamond_small, case_
     assert abs(Ad - Ad.T).max() == 0.0
 
 
-def test_colored_assembly_is_bitwise_reproducible(hip, case_with_diamond_small):
+@pytest.mark.parametrize("mode", [1, 3])
+def test_deterministic_assembly_modes_are_bitwise_reproducible(hip, mode, case_with_diamond_small):
     cfg, stack, mesh = case_with_diamond_small
     tag_to_k, tag_to_rc = material_tables(stack, mesh)
     tags = sorted(tag_to_k)
@@ -61,9 +62,55 @@ def test_colored_assembly_is_bitwise_reproducible(hip, case_with_diamond_small):
         with hip.HeatflowHIP(0) as be:
             be.set_mesh(mesh.coords, mesh.tris, mesh.tags)
             be.set_materials(tags, [tag_to_k[t] for t in tags], [tag_to_rc[t] for t in tags])
-            be.assemble(1e-7, hip.ASM_LDS_COLORED)
+            be.assemble(1e-7, mode)
             out.append(be.get_csr())
     assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+
+
+def _fan_mesh(nfan, ntags):
+    """A closed fan of `nfan` triangles around node 0 (row 0 holds nfan + 1 entries) next to a strip of quads
+    cut into triangles that carry `ntags` different cell tags."""
+    ang = 2 * np.pi * np.arange(nfan) / nfan
+    pts = [[5e-6, 5e-6]] + [[5e-6 + 1e-6 * np.cos(a), 5e-6 + 1e-6 * np.sin(a)] for a in ang]
+    tris = [[0, 1 + q, 1 + (q + 1) % nfan] for q in range(nfan)]
+    tags = [1] * nfan
+    base = len(pts)
+    for q in range(ntags + 1):
+        pts += [[20e-6 + q * 1e-6, 1e-6], [20e-6 + q * 1e-6, 2e-6]]
+    for q in range(ntags):
+        a, b, c, d = base + 2 * q, base + 2 * q + 1, base + 2 * q + 2, base + 2 * q + 3
+        tris += [[a, c, d], [a, d, b]]
+        tags += [2 + q, 2 + q]
+    return np.array(pts), np.array(tris, dtype=np.int32), np.array(tags, dtype=np.int32)
+
+
+@pytest.mark.parametrize("nfan,ntags", [(31, 3), (32, 3), (8, 70)])
+def test_row_gather_limits_and_its_fallback(hip, nfan, ntags):
+    """Row gather packs row positions into 5 bits and the cell tag into a 6-bit dictionary index: a row of 32
+    entries and 64 tags are the limits (first case: exactly at the row limit); beyond them HF_ASM_ROW_GATHER
+    runs the coloured LDS kernel instead.  Either way the matrices must equal the oracle's."""
+    from oracle import heat_oracle as ho
+    import scipy.sparse as sp
+
+    coords, tris, tags = _fan_mesh(nfan, ntags)
+    utags = sorted(set(tags.tolist()))
+    tk = {t: 1.0 + 0.37 * t for t in utags}
+    trc = {t: 2.0e6 + 1.0e4 * t for t in utags}
+    dt = 1e-7
+    with hip.HeatflowHIP(0) as be:
+        be.set_mesh(coords, tris, tags)
+        be.set_materials(utags, [tk[t] for t in utags], [trc[t] for t in utags])
+        be.assemble(dt, hip.ASM_ROW_GATHER)
+        rowptr, colidx, A, M = be.get_csr()
+    assert np.diff(rowptr).max() == nfan + 1
+    kappa, rho_c = ho.cell_coefficients(tags, tk, trc)
+    Me, Ke = ho.element_matrices(coords, tris.astype(np.int64), rho_c, kappa)
+    M_ref = ho.assemble_csr(len(coords), tris.astype(np.int64), Me)
+    A_ref = ho.assemble_csr(len(coords), tris.astype(np.int64), Me + dt * Ke)
+    assert np.array_equal(colidx, M_ref.indices)
+    assert _rel_row_err(M, M_ref.data, rowptr) < 1e-13 and _rel_row_err(A, A_ref.data, rowptr) < 1e-13
+    Ad = sp.csr_matrix((A, colidx, rowptr))
+    assert abs(Ad - Ad.T).max() == 0.0
 
 
 def test_dirichlet_elimination_and_spmv(hip, case_no_diamond_small):
@@ -785,7 +832,7 @@ def test_golden_fixture_fields_are_reproduced_by_the_hip_path(hip):
                 prob.step(t, only=[prob.bcs[3]])
                 worst = max(worst, float(np.abs(prob.state() - g["fields"][k]).max()))
             assert worst <= FIELD_TOL_K, f"precond {precond}: worst |dT| = {worst:.3e} K"
-            assert g["fields"][-1].max() > 310.0
+            assert g["fields"][-1].max() > 302.0           # the heating has started inside the fixture's 12 steps
         finally:
             prob.close()
 
@@ -820,6 +867,6 @@ def test_mesh_read_through_the_msh41_reader_runs_on_hip_and_matches_the_oracle(h
         for k in range(nsteps):
             prob.step((k + 1) * prob.dt, only=[prob.bcs[3]])
             assert np.abs(prob.state() - ref["fields"][k]).max() <= FIELD_TOL_K
-        assert ref["fields"][-1].max() > 400.0 and max(prob.iters) >= 3
+        assert ref["fields"][-1].max() > 320.0 and max(prob.iters) >= 3
     finally:
         prob.close()
