@@ -118,7 +118,7 @@ def build_problem_inputs(scale):
     return cfg, stack, mesh
 
 
-def make_problem(cfg, stack, coords, tris, tags, material_tags, k_sample, device_id, precond):
+def make_problem(cfg, stack, coords, tris, tags, material_tags, k_sample, device_id, precond, pattern=None):
     from heatflow_amd.bc import P1Space, RowDirichletBC
     from heatflow_amd.heating import HeatingCurve
     from heatflow_amd.solver import HeatProblem
@@ -133,7 +133,7 @@ def make_problem(cfg, stack, coords, tris, tags, material_tags, k_sample, device
     if k_sample is not None:
         tag_to_k[material_tags["p_sample"]] = float(k_sample)
     dt = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
-    return HeatProblem(coords, tris, tags, tag_to_k, tag_to_rc, dt, bcs, ic, device_id=device_id, precond=precond)
+    return HeatProblem(coords, tris, tags, tag_to_k, tag_to_rc, dt, bcs, ic, device_id=device_id, precond=precond, pattern=pattern)
 
 
 def cpu_baseline(cfg, mesh, n_sample_steps, first_step):
@@ -430,10 +430,14 @@ def main(argv=None):
             cfg = scale_mesh_sizes(yaml.safe_load(f), args.scale)
         stack = build_stack(cfg)
     (coords, tris, tags), mtags = ps.broadcast_mesh(arrays, mtags)
+    # N > 1: the connectivity tables (CSR pattern, column lists, assembly lists) are built by rank 0 only and broadcast too
+    share = {}
+    pattern = ps.shared_pattern((coords, tris, tags), dev_index, None, None, share) if world > 1 else None
 
     k_sample = None if world == 1 else 3.8 + 0.02 * rank
     precond = 1 if args.precond == "amg" else 0
-    prob = make_problem(cfg, stack, coords, tris, tags, mtags, k_sample, dev_index, precond)
+    prob = make_problem(cfg, stack, coords, tris, tags, mtags, k_sample, dev_index, precond, pattern)
+    setup_s = {"set_mesh": prob.mesh_seconds, "whole_problem": prob.setup_seconds, **share}
     be = prob.backend
     n, nnz, ne = be.n, be.nnz, be.n_e
     for bc in prob.bcs:
@@ -503,7 +507,7 @@ def main(argv=None):
             "solver": ("PCG + smoothed-aggregation multigrid V(1,1), damped-Jacobi smoothing" if precond else "Jacobi-PCG"),
             "pcg_rtol": prob.rtol, "pcg_iters_per_step_mean": float(np.mean(iters)), "pcg_iters_per_step_max": int(np.max(iters)),
             "points": "1 sweep point per GPU (kappa_sample = 3.8 + 0.02*rank)" if world > 1 else "1 run",
-            "gpu_ms_per_step_events": gpu_ms / args.steps}
+            "gpu_ms_per_step_events": gpu_ms / args.steps, "rank0_setup_s": setup_s}
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,

@@ -16,6 +16,260 @@
 // C ABI
 // ==========================================================================================
 namespace {
+
+// Everything the device needs that derives from the mesh connectivity alone.  hf_set_mesh builds it on the host,
+// hf_set_mesh_prebuilt takes it from a blob another context exported (hf_pattern_export): one rank builds, the
+// others of a sweep receive it over RCCL together with the mesh (reference parameter_sweep.py:401-446 re-reads
+// mesh.msh in every worker instead).
+struct MeshTables {
+  std::vector<int32_t> rowptr, colidx;
+  ColDict spmv;                 // compressed columns per TS-row SpMV chunk
+  RowGather rg;                 // row-gather assembly lists per RBA-row block (rg.ok = false: not available)
+  std::vector<char> tag_used;   // cell tags present in the mesh (index = tag)
+  int max_blk_nnz = 0;
+};
+
+constexpr char BLOB_MAGIC[8] = {'H', 'F', 'P', 'A', 'T', '0', '2', 0};
+struct BlobHeader {
+  char magic[8];
+  int64_t total_bytes, nnz;
+  int32_t n, ne, rba, ts, max_blk_nnz, tab_len, rg_ok, rg_max_dict, spmv_max_dict, reserved;
+  int64_t count[12];            // elements per section, in the order written below
+};
+inline size_t pad16(size_t b) { return (b + 15) & ~static_cast<size_t>(15); }
+
+// Upload the tables and size every buffer of the context for the mesh.
+int install_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int32_t* tri, const int32_t* tag, MeshTables& T) {
+  ctx->n = n; ctx->ne = ne; ctx->nnz = static_cast<int64_t>(T.colidx.size());
+  ctx->nchunks = (n + RB - 1) / RB;
+  ctx->nblk_a = (n + RBA - 1) / RBA;
+  ctx->P = std::min(ctx->nchunks, MAXP);
+  if (ctx->P >= 64) ctx->P &= ~7;          // multiple of 8: one equal group of workgroups per XCD
+  ctx->nchunks_s = (n + TS - 1) / TS;
+  ctx->Ps = std::min(ctx->nchunks_s, MAXP);
+  if (ctx->Ps >= 64) ctx->Ps &= ~7;
+  ctx->max_chunk_nnz_s = 0;
+  for (int c = 0; c < ctx->nchunks_s; ++c)
+    ctx->max_chunk_nnz_s = std::max(ctx->max_chunk_nnz_s, T.rowptr[std::min<int64_t>(n, (c + 1LL) * TS)] - T.rowptr[static_cast<size_t>(c) * TS]);
+  ctx->max_cdict = T.spmv.max_dict;
+  ctx->c16 = true;
+  if (const char* e = std::getenv("HEATFLOW_SPMV_C16")) ctx->c16 = (e[0] != '0');
+  if (static_cast<size_t>(ctx->max_chunk_nnz_s + ctx->max_cdict) * 8 > 64 * 1024) ctx->c16 = false;   // LDS window of the kernel
+  ctx->max_blk_nnz = T.max_blk_nnz;
+  if (static_cast<size_t>((ctx->max_blk_nnz + 1) & ~1) * 16 + (RBA + 1) * 4 > 160 * 1024)
+    return fail(ctx, HF_ERR_ARG, "row block holds %d nonzeros: LDS slab too large", ctx->max_blk_nnz);
+  ctx->tab_len = static_cast<int>(T.tag_used.size());
+  ctx->h_tag_used = T.tag_used;
+  ctx->assembled = false; ctx->have_mat = false;
+  ctx->h_tri.assign(tri, tri + 3 * static_cast<size_t>(ne));
+  ctx->h_tag.assign(tag, tag + ne);
+  ctx->owner_ready = false;
+  ctx->ncolors = 0; ctx->elist_len = 0;
+  dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent);
+
+  std::vector<int4> elem(ne);
+  for (int32_t e = 0; e < ne; ++e) elem[e] = make_int4(tri[3 * e], tri[3 * e + 1], tri[3 * e + 2], tag[e]);
+  HF_TRY(dev_alloc(ctx, &ctx->d_zr, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_elem, ne));
+  HF_TRY(dev_alloc(ctx, &ctx->d_kappa, ctx->tab_len));
+  HF_TRY(dev_alloc(ctx, &ctx->d_rhoc, ctx->tab_len));
+  HF_TRY(dev_alloc(ctx, &ctx->d_rowptr, n + 1));
+  HF_TRY(dev_alloc(ctx, &ctx->d_colidx, ctx->nnz));
+  HF_TRY(dev_alloc(ctx, &ctx->d_cdict_ptr, T.spmv.ptr.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_cdict, T.spmv.dict.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_cid, T.spmv.id.size()));
+  ctx->n_cdict = static_cast<int64_t>(T.spmv.dict.size());
+  HF_HIP(copy_sync(ctx, ctx->d_zr, zr, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+  ctx->rg_ok = T.rg.ok && rowgather_smem_bytes(T.max_blk_nnz, T.rg.cols.max_dict) <= 160 * 1024;
+  ctx->rg_grid = 0;
+  if (ctx->rg_ok) {
+    const RowGather& G = T.rg;
+    ctx->rg_max_dict = G.cols.max_dict;
+    ctx->h_rg_tags = G.tags;
+    ctx->n_rg_ell = static_cast<int64_t>(G.ell.size());
+    ctx->n_rg_dict = static_cast<int64_t>(G.cols.dict.size());
+    HF_TRY(dev_alloc(ctx, &ctx->d_rg_hdr, G.hdr.size()));
+    HF_TRY(dev_alloc(ctx, &ctx->d_rg_ell, G.ell.size()));
+    HF_TRY(dev_alloc(ctx, &ctx->d_rg_cid, G.cols.id.size() + 16));          // read in 16-byte vectors from an 8-aligned start
+    HF_TRY(dev_alloc(ctx, &ctx->d_rg_dict, G.cols.dict.size()));
+    HF_TRY(dev_alloc(ctx, &ctx->d_rg_zrb, G.cols.dict.size()));
+    HF_TRY(dev_alloc(ctx, &ctx->d_kappa_rg, 64));
+    HF_TRY(dev_alloc(ctx, &ctx->d_rhoc_rg, 64));
+    HF_HIP(copy_sync(ctx, ctx->d_rg_hdr, G.hdr.data(), sizeof(int4) * G.hdr.size(), hipMemcpyHostToDevice));
+    HF_HIP(copy_sync(ctx, ctx->d_rg_ell, G.ell.data(), sizeof(uint16_t) * G.ell.size(), hipMemcpyHostToDevice));
+    HF_HIP(hipMemsetAsync(ctx->d_rg_cid + G.cols.id.size(), 0, sizeof(uint16_t) * 16, ctx->stream));
+    HF_HIP(copy_sync(ctx, ctx->d_rg_cid, G.cols.id.data(), sizeof(uint16_t) * G.cols.id.size(), hipMemcpyHostToDevice));
+    HF_HIP(copy_sync(ctx, ctx->d_rg_dict, G.cols.dict.data(), sizeof(int32_t) * G.cols.dict.size(), hipMemcpyHostToDevice));
+    // per-block copies of the column lists' coordinates, gathered on the device
+    const int64_t total = ctx->n_rg_dict;
+    hipLaunchKernelGGL(k_gather_coords, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, ctx->stream, total, ctx->d_rg_dict,
+                       ctx->d_zr, ctx->d_rg_zrb);
+    HF_HIP(hipGetLastError());
+  }
+  HF_TRY(dev_alloc(ctx, &ctx->d_M, ctx->nnz));
+  HF_TRY(dev_alloc(ctx, &ctx->d_A, ctx->nnz));
+  HF_TRY(dev_alloc(ctx, &ctx->d_dinv, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_u, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_uprev, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_ustart, n));
+  ctx->have_prev = false;
+  free_responses(ctx);
+  HF_TRY(dev_alloc(ctx, &ctx->d_b, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_r, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_p, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_Ap, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_tmp, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_z, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_z2, n));
+  free_amg(ctx);
+  HF_HIP(copy_sync(ctx, ctx->d_elem, elem.data(), sizeof(int4) * ne, hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_rowptr, T.rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_colidx, T.colidx.data(), sizeof(int32_t) * ctx->nnz, hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_cdict_ptr, T.spmv.ptr.data(), sizeof(int32_t) * T.spmv.ptr.size(), hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_cdict, T.spmv.dict.data(), sizeof(int32_t) * T.spmv.dict.size(), hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_cid, T.spmv.id.data(), sizeof(uint16_t) * T.spmv.id.size(), hipMemcpyHostToDevice));
+  HF_HIP(hipMemsetAsync(ctx->d_u, 0, sizeof(double) * n, ctx->stream));
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->h_rowptr.swap(T.rowptr);
+  ctx->h_colidx.swap(T.colidx);
+  // a new mesh invalidates the Dirichlet set
+  ctx->nbc = 0; ctx->nlift = 0; ctx->nlift_rows = 0;
+  ctx->have_mesh = true;
+  ctx->pred_iters = 0;
+  ctx->flux_ready = false;
+  if (!ctx->rg_ok) HF_TRY(ensure_owner_lists(ctx));   // the scatter kernels are this mesh's only assembly path: report their limits now
+  return HF_OK;
+}
+
+// ---- serialised tables (hf_pattern_export / hf_set_mesh_prebuilt): header, then 16-byte aligned sections
+struct Section { const void* src; size_t bytes; bool on_device; };
+
+void list_sections(const hf_ctx* c, Section out[12], int64_t count[12]) {
+  const int nblk = c->nblk_a, nch = c->nchunks_s;
+  const bool rg = c->rg_ok;
+  const Section s[12] = {
+      {c->h_rowptr.data(), sizeof(int32_t) * (static_cast<size_t>(c->n) + 1), false},
+      {c->h_colidx.data(), sizeof(int32_t) * static_cast<size_t>(c->nnz), false},
+      {c->d_cdict_ptr, sizeof(int32_t) * (static_cast<size_t>(nch) + 1), true},
+      {c->d_cdict, sizeof(int32_t) * static_cast<size_t>(c->n_cdict), true},
+      {c->d_cid, sizeof(uint16_t) * static_cast<size_t>(c->nnz), true},
+      {c->h_tag_used.data(), c->h_tag_used.size(), false},
+      {c->d_rg_hdr, rg ? sizeof(int4) * 2 * static_cast<size_t>(nblk) : 0, true},
+      {c->d_rg_ell, rg ? sizeof(uint16_t) * static_cast<size_t>(c->n_rg_ell) : 0, true},
+      {c->h_rg_tags.data(), rg ? sizeof(int32_t) * c->h_rg_tags.size() : 0, false},
+      {c->d_rg_dict, rg ? sizeof(int32_t) * static_cast<size_t>(c->n_rg_dict) : 0, true},
+      {c->d_rg_cid, rg ? sizeof(uint16_t) * static_cast<size_t>(c->nnz) : 0, true},
+      {nullptr, 0, false}};
+  const size_t unit[12] = {4, 4, 4, 4, 2, 1, 16, 2, 4, 4, 2, 1};
+  for (int k = 0; k < 12; ++k) { out[k] = s[k]; count[k] = static_cast<int64_t>(s[k].bytes / unit[k]); }
+}
+
+int64_t mesh_tables_bytes(const hf_ctx* c) {
+  Section s[12];
+  int64_t cnt[12];
+  list_sections(c, s, cnt);
+  size_t total = pad16(sizeof(BlobHeader));
+  for (int k = 0; k < 12; ++k) total += pad16(s[k].bytes);
+  return static_cast<int64_t>(total);
+}
+
+int write_mesh_tables(hf_ctx* ctx, unsigned char* dst) {
+  Section s[12];
+  BlobHeader h{};
+  list_sections(ctx, s, h.count);
+  std::memcpy(h.magic, BLOB_MAGIC, 8);
+  h.total_bytes = mesh_tables_bytes(ctx);
+  h.nnz = ctx->nnz; h.n = ctx->n; h.ne = ctx->ne; h.rba = RBA; h.ts = TS; h.max_blk_nnz = ctx->max_blk_nnz;
+  h.tab_len = ctx->tab_len; h.rg_ok = ctx->rg_ok ? 1 : 0; h.rg_max_dict = ctx->rg_max_dict; h.spmv_max_dict = ctx->max_cdict;
+  std::memset(dst, 0, static_cast<size_t>(h.total_bytes));
+  std::memcpy(dst, &h, sizeof h);
+  size_t at = pad16(sizeof(BlobHeader));
+  for (int k = 0; k < 12; ++k) {
+    if (s[k].bytes) {
+      if (s[k].on_device) HF_HIP(hipMemcpyAsync(dst + at, s[k].src, s[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
+      else std::memcpy(dst + at, s[k].src, s[k].bytes);
+    }
+    at += pad16(s[k].bytes);
+  }
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  return HF_OK;
+}
+
+template <typename T>
+bool take_section(const unsigned char* blob, int64_t bytes, size_t& at, int64_t count, std::vector<T>& out) {
+  if (count < 0) return false;
+  const size_t need = sizeof(T) * static_cast<size_t>(count);
+  if (at + need > static_cast<size_t>(bytes)) return false;
+  out.resize(static_cast<size_t>(count));
+  if (need) std::memcpy(out.data(), blob + at, need);
+  at += pad16(need);
+  return true;
+}
+
+int parse_mesh_tables(hf_ctx* ctx, const unsigned char* blob, int64_t bytes, int32_t n, int32_t ne, MeshTables& T) {
+  BlobHeader h;
+  if (bytes < static_cast<int64_t>(sizeof h)) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: blob too short");
+  std::memcpy(&h, blob, sizeof h);
+  if (std::memcmp(h.magic, BLOB_MAGIC, 8) != 0) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: not a pattern blob of this library version");
+  if (h.total_bytes != bytes) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: blob says %lld bytes, %lld given", (long long)h.total_bytes, (long long)bytes);
+  if (h.n != n || h.ne != ne) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: blob was exported for a mesh of %d nodes / %d triangles, not %d / %d", h.n, h.ne, n, ne);
+  if (h.rba != RBA || h.ts != TS) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: blob built for other block sizes");
+  size_t at = pad16(sizeof(BlobHeader));
+  std::vector<int4> hdr;
+  bool ok = take_section(blob, bytes, at, h.count[0], T.rowptr) && take_section(blob, bytes, at, h.count[1], T.colidx) &&
+            take_section(blob, bytes, at, h.count[2], T.spmv.ptr) && take_section(blob, bytes, at, h.count[3], T.spmv.dict) &&
+            take_section(blob, bytes, at, h.count[4], T.spmv.id) && take_section(blob, bytes, at, h.count[5], T.tag_used) &&
+            take_section(blob, bytes, at, h.count[6], T.rg.hdr) && take_section(blob, bytes, at, h.count[7], T.rg.ell) &&
+            take_section(blob, bytes, at, h.count[8], T.rg.tags) && take_section(blob, bytes, at, h.count[9], T.rg.cols.dict) &&
+            take_section(blob, bytes, at, h.count[10], T.rg.cols.id);
+  const int nblk = (n + RBA - 1) / RBA, nch = (n + TS - 1) / TS;
+  ok = ok && T.rowptr.size() == static_cast<size_t>(n) + 1 && T.rowptr[0] == 0 && T.rowptr[n] == h.nnz &&
+       T.colidx.size() == static_cast<size_t>(h.nnz) && T.spmv.ptr.size() == static_cast<size_t>(nch) + 1 &&
+       T.spmv.id.size() == T.colidx.size() && static_cast<int>(T.tag_used.size()) == h.tab_len && h.tab_len > 0 &&
+       !T.spmv.ptr.empty() && T.spmv.ptr.back() == static_cast<int32_t>(T.spmv.dict.size());
+  if (ok && h.rg_ok)
+    ok = T.rg.hdr.size() == 2 * static_cast<size_t>(nblk) && T.rg.cols.id.size() == T.colidx.size() && !T.rg.tags.empty() &&
+         T.rg.tags.size() <= 64 && h.rg_max_dict > 0 && h.rg_max_dict <= RBA * RG_NX;
+  if (!ok) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: blob sections do not fit the mesh");
+  // every index the kernels follow without a bounds check is verified once here
+  for (int32_t i = 0; i < n && ok; ++i) ok = T.rowptr[i + 1] > T.rowptr[i];
+  for (size_t k = 0; k < T.colidx.size() && ok; ++k) ok = T.colidx[k] >= 0 && T.colidx[k] < n;
+  for (size_t k = 0; k < T.spmv.dict.size() && ok; ++k) ok = T.spmv.dict[k] >= 0 && T.spmv.dict[k] < n;
+  for (int c = 0; c < nch && ok; ++c) {
+    const int nd = T.spmv.ptr[c + 1] - T.spmv.ptr[c];
+    ok = nd > 0 && nd <= h.spmv_max_dict;
+    for (int32_t k = T.rowptr[static_cast<size_t>(c) * TS]; k < T.rowptr[std::min<int64_t>(n, (c + 1LL) * TS)] && ok; ++k) ok = T.spmv.id[k] < nd;
+  }
+  if (ok && h.rg_ok) {
+    for (size_t k = 0; k < T.rg.cols.dict.size() && ok; ++k) ok = T.rg.cols.dict[k] >= 0 && T.rg.cols.dict[k] < n;
+    const int64_t ell16 = static_cast<int64_t>(T.rg.ell.size() / 8);
+    for (int b = 0; b < nblk && ok; ++b) {
+      const int4 A = T.rg.hdr[2 * b], B = T.rg.hdr[2 * b + 1];
+      const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
+      ok = A.x == T.rowptr[r0] && A.y == T.rowptr[r1] - T.rowptr[r0] && A.z >= 0 && A.w > 0 && A.w <= h.rg_max_dict &&
+           static_cast<size_t>(A.z) + A.w <= T.rg.cols.dict.size() && B.x >= 0 && B.y >= 1 &&
+           static_cast<int64_t>(B.x) + static_cast<int64_t>(B.y) * RBA <= ell16 && B.z >= 0 && B.z + (r1 - r0) <= A.w && B.w == r1 - r0 &&
+           A.y <= h.max_blk_nnz;
+      for (int32_t k = A.x; k < A.x + A.y && ok; ++k) ok = T.rg.cols.id[k] < A.w;
+      for (int32_t i = r0; i < r1 && ok; ++i) {
+        const int len = T.rowptr[i + 1] - T.rowptr[i];
+        ok = len <= 32;
+        for (int g = 0; g < B.y && ok; ++g)
+          for (int j = 0; j < 8 && ok; ++j) {
+            const unsigned e = T.rg.ell[(static_cast<size_t>(B.x) + static_cast<size_t>(g) * RBA + (i - r0)) * 8 + j];
+            ok = e == 0xFFFFu || (static_cast<int>(e & 31u) < len && static_cast<int>((e >> 5) & 31u) < len && (e >> 10) < T.rg.tags.size());
+          }
+      }
+    }
+  }
+  if (!ok) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: blob holds an index outside its range");
+  T.spmv.max_dict = h.spmv_max_dict;
+  T.max_blk_nnz = h.max_blk_nnz;
+  T.rg.ok = h.rg_ok != 0;
+  T.rg.cols.max_dict = h.rg_max_dict;
+  return HF_OK;
+}
+
 // coefficient tables of the row-gather kernel: indexed by position in the mesh's tag dictionary
 int upload_rg_tables(hf_ctx* ctx, const std::vector<double>& by_tag_k, const std::vector<double>* by_tag_c) {
   if (!ctx->rg_ok) return HF_OK;
@@ -71,7 +325,7 @@ int hf_destroy(hf_ctx* ctx) {
   (void)hipSetDevice(ctx->dev);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   dev_free(&ctx->d_zr); dev_free(&ctx->d_elem); dev_free(&ctx->d_kappa); dev_free(&ctx->d_rhoc);
-  dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_cdict_ptr); dev_free(&ctx->d_cdict); dev_free(&ctx->d_cid); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent); dev_free(&ctx->d_rg_hdr); dev_free(&ctx->d_rg_ell); dev_free(&ctx->d_rg_cid); dev_free(&ctx->d_rg_zrb); dev_free(&ctx->d_kappa_rg); dev_free(&ctx->d_rhoc_rg); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
+  dev_free(&ctx->d_rowptr); dev_free(&ctx->d_colidx); dev_free(&ctx->d_cdict_ptr); dev_free(&ctx->d_cdict); dev_free(&ctx->d_cid); dev_free(&ctx->d_blk_eptr); dev_free(&ctx->d_blk_cptr); dev_free(&ctx->d_blk_ent); dev_free(&ctx->d_rg_hdr); dev_free(&ctx->d_rg_ell); dev_free(&ctx->d_rg_cid); dev_free(&ctx->d_rg_dict); dev_free(&ctx->d_rg_zrb); dev_free(&ctx->d_kappa_rg); dev_free(&ctx->d_rhoc_rg); dev_free(&ctx->d_M); dev_free(&ctx->d_A); dev_free(&ctx->d_dinv);
   dev_free(&ctx->d_bc_dofs); dev_free(&ctx->d_g); dev_free(&ctx->d_lift_rows); dev_free(&ctx->d_lift_ptr);
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_uprev); dev_free(&ctx->d_ustart);
@@ -103,115 +357,47 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
     const double d = (p1[0] - p0[0]) * (p2[1] - p0[1]) - (p2[0] - p0[0]) * (p1[1] - p0[1]);
     if (!(d != 0.0)) return fail(ctx, HF_ERR_ARG, "hf_set_mesh: degenerate triangle %d", e);
   }
+  MeshTables T;
   Pattern P;
-  HF_TRY(build_pattern(ctx, n, ne, tri, tag, P));
-  ctx->n = n; ctx->ne = ne; ctx->nnz = static_cast<int64_t>(P.colidx.size());
-  ctx->nchunks = (n + RB - 1) / RB;
-  ctx->nblk_a = (n + RBA - 1) / RBA;
-  ctx->P = std::min(ctx->nchunks, MAXP);
-  if (ctx->P >= 64) ctx->P &= ~7;          // multiple of 8: one equal group of workgroups per XCD
-  ctx->nchunks_s = (n + TS - 1) / TS;
-  ctx->Ps = std::min(ctx->nchunks_s, MAXP);
-  if (ctx->Ps >= 64) ctx->Ps &= ~7;
-  ctx->max_chunk_nnz_s = 0;
-  for (int c = 0; c < ctx->nchunks_s; ++c)
-    ctx->max_chunk_nnz_s = std::max(ctx->max_chunk_nnz_s, P.rowptr[std::min<int64_t>(n, (c + 1LL) * TS)] - P.rowptr[c * TS]);
-  // compressed columns per SpMV chunk: sorted unique columns + 16-bit position per nonzero
-  ColDict sd;
-  if (!build_coldict(P.rowptr, P.colidx, n, TS, sd)) return fail(ctx, HF_ERR_ARG, "an SpMV chunk touches more than 65535 columns (16-bit positions)");
-  std::vector<int32_t>& cdict_ptr = sd.ptr;
-  std::vector<int32_t>& cdict = sd.dict;
-  std::vector<uint16_t>& cid = sd.id;
-  ctx->max_cdict = sd.max_dict;
-  if (const char* e = std::getenv("HEATFLOW_SPMV_C16")) ctx->c16 = (e[0] != '0');
-  if (static_cast<size_t>(ctx->max_chunk_nnz_s + ctx->max_cdict) * 8 > 64 * 1024) ctx->c16 = false;   // LDS window of the kernel
-  ctx->max_blk_nnz = P.max_blk_nnz;
-  ctx->ncolors = P.ncolors;
-  ctx->elist_len = static_cast<int64_t>(P.blk_elist.size());
-  if (static_cast<size_t>((ctx->max_blk_nnz + 1) & ~1) * 16 + (RBA + 1) * 4 > 160 * 1024)
-    return fail(ctx, HF_ERR_ARG, "row block holds %d nonzeros: LDS slab too large", ctx->max_blk_nnz);
-  ctx->tab_len = maxtag + 1;
-  ctx->h_tag_used.assign(ctx->tab_len, 0);
-  for (int32_t e = 0; e < ne; ++e) ctx->h_tag_used[tag[e]] = 1;
-  ctx->assembled = false; ctx->have_mat = false;
+  HF_TRY(build_csr(ctx, n, ne, tri, P));
+  build_rowgather(n, ne, tri, tag, P);
+  if (!build_coldict(P.rowptr, P.colidx, n, TS, T.spmv)) return fail(ctx, HF_ERR_ARG, "an SpMV chunk touches more than 65535 columns (16-bit positions)");
+  T.rowptr.swap(P.rowptr);
+  T.colidx.swap(P.colidx);
+  T.max_blk_nnz = P.max_blk_nnz;
+  T.rg = std::move(P.rg);
+  T.tag_used.assign(static_cast<size_t>(maxtag) + 1, 0);
+  for (int32_t e = 0; e < ne; ++e) T.tag_used[tag[e]] = 1;
+  return install_mesh(ctx, n, ne, zr, tri, tag, T);
+}
 
-  std::vector<int4> elem(ne);
-  for (int32_t e = 0; e < ne; ++e) elem[e] = make_int4(tri[3 * e], tri[3 * e + 1], tri[3 * e + 2], tag[e]);
-  HF_TRY(dev_alloc(ctx, &ctx->d_zr, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_elem, ne));
-  HF_TRY(dev_alloc(ctx, &ctx->d_kappa, ctx->tab_len));
-  HF_TRY(dev_alloc(ctx, &ctx->d_rhoc, ctx->tab_len));
-  HF_TRY(dev_alloc(ctx, &ctx->d_rowptr, n + 1));
-  HF_TRY(dev_alloc(ctx, &ctx->d_colidx, ctx->nnz));
-  HF_TRY(dev_alloc(ctx, &ctx->d_cdict_ptr, cdict_ptr.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_cdict, cdict.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_cid, cid.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_blk_eptr, P.blk_eptr.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_blk_cptr, P.blk_cptr.size()));
-  HF_TRY(dev_alloc(ctx, &ctx->d_blk_ent, P.blk_ent.size()));
-  ctx->rg_ok = P.rg.ok && rowgather_smem_bytes(P.max_blk_nnz, P.rg.cols.max_dict) <= 160 * 1024;
-  ctx->rg_grid = 0;
-  if (ctx->rg_ok) {
-    const RowGather& G = P.rg;
-    ctx->rg_max_dict = G.cols.max_dict;
-    ctx->h_rg_tags = G.tags;
-    HF_TRY(dev_alloc(ctx, &ctx->d_rg_hdr, G.hdr.size()));
-    HF_TRY(dev_alloc(ctx, &ctx->d_rg_ell, G.ell.size()));
-    HF_TRY(dev_alloc(ctx, &ctx->d_rg_cid, G.cols.id.size() + 16));          // read in 16-byte vectors from an 8-aligned start
-    HF_TRY(dev_alloc(ctx, &ctx->d_rg_zrb, G.cols.dict.size()));
-    HF_TRY(dev_alloc(ctx, &ctx->d_kappa_rg, 64));
-    HF_TRY(dev_alloc(ctx, &ctx->d_rhoc_rg, 64));
-    HF_HIP(copy_sync(ctx, ctx->d_rg_hdr, G.hdr.data(), sizeof(int4) * G.hdr.size(), hipMemcpyHostToDevice));
-    HF_HIP(copy_sync(ctx, ctx->d_rg_ell, G.ell.data(), sizeof(uint16_t) * G.ell.size(), hipMemcpyHostToDevice));
-    HF_HIP(hipMemsetAsync(ctx->d_rg_cid + G.cols.id.size(), 0, sizeof(uint16_t) * 16, ctx->stream));
-    HF_HIP(copy_sync(ctx, ctx->d_rg_cid, G.cols.id.data(), sizeof(uint16_t) * G.cols.id.size(), hipMemcpyHostToDevice));
-  }
-  HF_TRY(dev_alloc(ctx, &ctx->d_M, ctx->nnz));
-  HF_TRY(dev_alloc(ctx, &ctx->d_A, ctx->nnz));
-  HF_TRY(dev_alloc(ctx, &ctx->d_dinv, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_u, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_uprev, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_ustart, n));
-  ctx->have_prev = false;
-  free_responses(ctx);
-  HF_TRY(dev_alloc(ctx, &ctx->d_b, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_r, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_p, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_Ap, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_tmp, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_z, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_z2, n));
-  free_amg(ctx);
-  HF_HIP(copy_sync(ctx, ctx->d_zr, zr, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
-  if (ctx->rg_ok) {   // per-block copies of the column lists' coordinates, gathered on the device
-    const std::vector<int32_t>& dict = P.rg.cols.dict;
-    DevTemp<int32_t> t_dict;
-    HF_TRY(dev_alloc(ctx, &t_dict.p, dict.size()));
-    HF_HIP(copy_sync(ctx, t_dict.p, dict.data(), sizeof(int32_t) * dict.size(), hipMemcpyHostToDevice));
-    const int64_t total = static_cast<int64_t>(dict.size());
-    hipLaunchKernelGGL(k_gather_coords, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, ctx->stream, total, t_dict.p,
-                       ctx->d_zr, ctx->d_rg_zrb);
-    HF_HIP(hipGetLastError());
-    HF_HIP(hipStreamSynchronize(ctx->stream));
-  }
-  HF_HIP(copy_sync(ctx, ctx->d_elem, elem.data(), sizeof(int4) * ne, hipMemcpyHostToDevice));
-  HF_HIP(copy_sync(ctx, ctx->d_rowptr, P.rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
-  HF_HIP(copy_sync(ctx, ctx->d_colidx, P.colidx.data(), sizeof(int32_t) * ctx->nnz, hipMemcpyHostToDevice));
-  HF_HIP(copy_sync(ctx, ctx->d_cdict_ptr, cdict_ptr.data(), sizeof(int32_t) * cdict_ptr.size(), hipMemcpyHostToDevice));
-  HF_HIP(copy_sync(ctx, ctx->d_cdict, cdict.data(), sizeof(int32_t) * cdict.size(), hipMemcpyHostToDevice));
-  HF_HIP(copy_sync(ctx, ctx->d_cid, cid.data(), sizeof(uint16_t) * cid.size(), hipMemcpyHostToDevice));
-  HF_HIP(copy_sync(ctx, ctx->d_blk_eptr, P.blk_eptr.data(), sizeof(int32_t) * P.blk_eptr.size(), hipMemcpyHostToDevice));
-  HF_HIP(copy_sync(ctx, ctx->d_blk_cptr, P.blk_cptr.data(), sizeof(int32_t) * P.blk_cptr.size(), hipMemcpyHostToDevice));
-  HF_HIP(copy_sync(ctx, ctx->d_blk_ent, P.blk_ent.data(), sizeof(int2) * P.blk_ent.size(), hipMemcpyHostToDevice));
-  HF_HIP(hipMemsetAsync(ctx->d_u, 0, sizeof(double) * n, ctx->stream));
-  HF_HIP(hipStreamSynchronize(ctx->stream));
-  ctx->h_rowptr.swap(P.rowptr);
-  ctx->h_colidx.swap(P.colidx);
-  // a new mesh invalidates the Dirichlet set
-  ctx->nbc = 0; ctx->nlift = 0; ctx->nlift_rows = 0;
-  ctx->have_mesh = true;
-  ctx->pred_iters = 0;
-  ctx->flux_ready = false;
+int hf_set_mesh_prebuilt(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int32_t* tri, const int32_t* tag,
+                         const void* blob, int64_t bytes) {
+  if (!ctx) return HF_ERR_ARG;
+  if (!zr || !tri || !tag || !blob || n <= 0 || ne <= 0 || bytes <= 0) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: null pointer or empty mesh");
+  HF_HIP(hipSetDevice(ctx->dev));
+  std::vector<unsigned char> host(static_cast<size_t>(bytes));     // the blob may live on the host or on a device
+  HF_HIP(hipMemcpy(host.data(), blob, static_cast<size_t>(bytes), hipMemcpyDefault));
+  MeshTables T;
+  HF_TRY(parse_mesh_tables(ctx, host.data(), bytes, n, ne, T));
+  return install_mesh(ctx, n, ne, zr, tri, tag, T);
+}
+
+int hf_pattern_export_size(hf_ctx* ctx, int64_t* bytes) {
+  if (!ctx || !bytes) return HF_ERR_ARG;
+  if (!ctx->have_mesh) return fail(ctx, HF_ERR_STATE, "hf_pattern_export_size before hf_set_mesh");
+  *bytes = mesh_tables_bytes(ctx);
+  return HF_OK;
+}
+
+int hf_pattern_export(hf_ctx* ctx, void* blob, int64_t bytes) {
+  if (!ctx || !blob) return HF_ERR_ARG;
+  if (!ctx->have_mesh) return fail(ctx, HF_ERR_STATE, "hf_pattern_export before hf_set_mesh");
+  if (bytes != mesh_tables_bytes(ctx)) return fail(ctx, HF_ERR_ARG, "hf_pattern_export: buffer of %lld bytes, need %lld", (long long)bytes, (long long)mesh_tables_bytes(ctx));
+  HF_HIP(hipSetDevice(ctx->dev));
+  std::vector<unsigned char> host(static_cast<size_t>(bytes));
+  HF_TRY(write_mesh_tables(ctx, host.data()));
+  HF_HIP(hipMemcpy(blob, host.data(), static_cast<size_t>(bytes), hipMemcpyDefault));   // host or device destination
   return HF_OK;
 }
 
@@ -369,15 +555,17 @@ int hf_flux_setup(hf_ctx* ctx) {
   HF_TRY(dev_alloc(ctx, &ctx->d_bz, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_br, n));
   // M_r(1): the element kernel with rho_c = 1, kappa = 0, dt = 0 (its A output = M goes to scratch)
+  const int tab = ctx->rg_ok ? 64 : ctx->tab_len;
   DevTemp<double> t_one, t_zero, t_scratch;
   double *&d_one = t_one.p, *&d_zero = t_zero.p, *&d_scratch = t_scratch.p;
-  HF_TRY(dev_alloc(ctx, &d_one, ctx->tab_len));
-  HF_TRY(dev_alloc(ctx, &d_zero, ctx->tab_len));
+  HF_TRY(dev_alloc(ctx, &d_one, tab));
+  HF_TRY(dev_alloc(ctx, &d_zero, tab));
   HF_TRY(dev_alloc(ctx, &d_scratch, ctx->nnz));
-  std::vector<double> ones(ctx->tab_len, 1.0), zeros(ctx->tab_len, 0.0);
-  HF_HIP(copy_sync(ctx, d_one, ones.data(), sizeof(double) * ctx->tab_len, hipMemcpyHostToDevice));
-  HF_HIP(copy_sync(ctx, d_zero, zeros.data(), sizeof(double) * ctx->tab_len, hipMemcpyHostToDevice));
-  HF_TRY(launch_assemble_lds(ctx, true, d_zero, d_one, 0.0, ctx->d_M1, d_scratch));
+  std::vector<double> ones(tab, 1.0), zeros(tab, 0.0);
+  HF_HIP(copy_sync(ctx, d_one, ones.data(), sizeof(double) * tab, hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, d_zero, zeros.data(), sizeof(double) * tab, hipMemcpyHostToDevice));
+  if (ctx->rg_ok) HF_TRY(launch_assemble_rows(ctx, d_zero, d_one, 0.0, ctx->d_M1, d_scratch));
+  else HF_TRY(launch_assemble_lds(ctx, true, d_zero, d_one, 0.0, ctx->d_M1, d_scratch));
   hipLaunchKernelGGL(k_dinv, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ctx->d_rowptr, ctx->d_colidx,
                      ctx->d_M1, ctx->d_dinv1);
   HF_HIP(hipMemsetAsync(ctx->d_gz, 0, sizeof(double) * n, ctx->stream));
@@ -394,9 +582,19 @@ int hf_flux_solve(hf_ctx* ctx, int32_t components, double rtol, int32_t max_it, 
   if (!ctx->flux_ready) return fail(ctx, HF_ERR_STATE, "hf_flux_solve before hf_flux_setup");
   if (max_it <= 0 || rtol < 0 || components < 0 || components > 3) return fail(ctx, HF_ERR_ARG, "hf_flux_solve: bad arguments");
   HF_HIP(hipSetDevice(ctx->dev));
-  hipLaunchKernelGGL(k_grad_rhs, dim3(ctx->nblk_a), dim3(RBA), 0, ctx->stream, ctx->n, ctx->d_blk_eptr, ctx->d_blk_ent,
-                     ctx->d_zr, ctx->d_u, ctx->d_bz, ctx->d_br);
-  HF_HIP(hipGetLastError());
+  if (ctx->rg_ok) {
+    const int capd = ctx->rg_max_dict;
+    const size_t sm = static_cast<size_t>(capd) * 16 + static_cast<size_t>(capd + (capd & 1)) * 8 + (RBA + 4) * 4 +
+                      (static_cast<size_t>((ctx->max_blk_nnz + 1) & ~1) / 8 + 3) * 16;
+    const int grid = std::min(ctx->nblk_a, 2048);
+    hipLaunchKernelGGL(k_grad_rows, dim3(grid), dim3(RBA), sm, ctx->stream, ctx->nblk_a, capd, ctx->d_rg_hdr,
+                       reinterpret_cast<const uint4*>(ctx->d_rg_ell), reinterpret_cast<const uint4*>(ctx->d_rg_cid), ctx->d_rg_zrb,
+                       ctx->d_rg_dict, ctx->d_rowptr, ctx->d_u, ctx->d_bz, ctx->d_br);
+  } else {
+    HF_TRY(ensure_owner_lists(ctx));
+    hipLaunchKernelGGL(k_grad_rhs, dim3(ctx->nblk_a), dim3(RBA), 0, ctx->stream, ctx->n, ctx->d_blk_eptr, ctx->d_blk_ent,
+                       ctx->d_zr, ctx->d_u, ctx->d_bz, ctx->d_br);
+  }
   if (iters) iters[0] = iters[1] = 0;
   ctx->flux_valid = 0;
   // one scalar mass-matrix solve per wanted component, each warm-started from its previous projection

@@ -70,9 +70,11 @@ struct hf_ctx {
   double dt = 0.0;
   int mode = 0;
 
-  // host copies of the pattern (needed to build lifting structures)
-  std::vector<int32_t> h_rowptr, h_colidx;
+  // host copies of the pattern (needed to build lifting structures and the multigrid hierarchy) and of the
+  // elements (the lists of the LDS scatter kernels are built from them on first use)
+  std::vector<int32_t> h_rowptr, h_colidx, h_tri, h_tag;
   std::vector<char> h_tag_used;
+  bool owner_ready = false;
 
   // device: mesh
   double2* d_zr = nullptr;
@@ -90,8 +92,10 @@ struct hf_ctx {
   bool rg_ok = false;
   int4* d_rg_hdr = nullptr;
   uint16_t *d_rg_ell = nullptr, *d_rg_cid = nullptr;
+  int32_t* d_rg_dict = nullptr;     // the blocks' column lists (global node ids)
   double2* d_rg_zrb = nullptr;      // coordinates of every block's column list (own rows + halo)
   int rg_max_dict = 0, rg_grid = 0;
+  int64_t n_rg_ell = 0, n_rg_dict = 0, n_cdict = 0;
   std::vector<int32_t> h_rg_tags;
   double *d_kappa_rg = nullptr, *d_rhoc_rg = nullptr;
   // device: matrices

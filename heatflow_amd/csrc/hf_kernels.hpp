@@ -358,6 +358,59 @@ __global__ __launch_bounds__(RBA) void k_assemble_rows(int nblk, int cap /* slab
   }
 }
 
+// Read-flux projection right-hand sides by row gather (same lists and staging as k_assemble_rows, plus the block's
+// slice of the state u): b_c[i] = sum over the triangles at node i of (d_c T)_e * |K| (2 r_i + r_j + r_k)/12, summed
+// in list order in a register - no LDS accumulation, no atomics, bitwise reproducible.
+__global__ __launch_bounds__(RBA) void k_grad_rows(int nblk, int capd, const int4* __restrict__ hdr, const uint4* __restrict__ ell,
+                                                   const uint4* __restrict__ cid16, const double2* __restrict__ zrb,
+                                                   const int32_t* __restrict__ dict, const int32_t* __restrict__ rowptr,
+                                                   const double* __restrict__ u, double* __restrict__ bz, double* __restrict__ br) {
+  extern __shared__ double smem[];
+  double2* sXd = reinterpret_cast<double2*>(smem);
+  double* sU = smem + 2 * capd;
+  int* sR = reinterpret_cast<int*>(sU + capd + (capd & 1));
+  uint4* sC4 = reinterpret_cast<uint4*>(sR + RBA + 4);
+  const uint16_t* sC = reinterpret_cast<const uint16_t*>(sC4);
+  const int t = threadIdx.x;
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int4 cA = hdr[2 * blk], cB = hdr[2 * blk + 1];
+    const int c0 = cA.x >> 3, nc = ((cA.x + cA.y + 7) >> 3) - c0;
+    for (int i = t; i < nc; i += RBA) sC4[i] = cid16[c0 + i];
+    for (int i = t; i < cA.w; i += RBA) { sXd[i] = zrb[cA.z + i]; sU[i] = u[dict[cA.z + i]]; }
+    if (t < cB.w) sR[t] = rowptr[blk * RBA + t] - cA.x;
+    __syncthreads();
+    if (t < cB.w) {
+#pragma clang fp contract(off)
+      const int sbase = sR[t] + (cA.x & 7);
+      const int ci = cB.z + t;
+      const double2 Pi = sXd[ci];
+      const double ui = sU[ci];
+      double az = 0.0, ar = 0.0;
+      for (int g = 0; g < cB.y; ++g) {
+        const uint4 ev = ell[cB.x + g * RBA + t];
+        const unsigned w[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const unsigned e = (w[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
+          if (e == 0xFFFFu) continue;
+          const int cj = sC[sbase + (e & 31u)], ck = sC[sbase + ((e >> 5) & 31u)];
+          const double2 Pj = sXd[cj], Pk = sXd[ck];
+          const double uj = sU[cj], uk = sU[ck];
+          const double d = (Pj.x - Pi.x) * (Pk.y - Pi.y) - (Pk.x - Pi.x) * (Pj.y - Pi.y);
+          const double gz = (ui * (Pj.y - Pk.y) + uj * (Pk.y - Pi.y) + uk * (Pi.y - Pj.y)) / d;
+          const double gr = (ui * (Pk.x - Pj.x) + uj * (Pi.x - Pk.x) + uk * (Pj.x - Pi.x)) / d;
+          const double wgt = 0.5 * fabs(d) * (Pi.y + ((Pi.y + Pj.y) + Pk.y)) / 12.0;
+          az += gz * wgt;
+          ar += gr * wgt;
+        }
+      }
+      bz[blk * RBA + t] = az;
+      br[blk * RBA + t] = ar;
+    }
+    __syncthreads();
+  }
+}
+
 // per-block copy of the coordinates of each block's column list (hf_set_mesh, once)
 __global__ void k_gather_coords(int64_t total, const int32_t* __restrict__ dict, const double2* __restrict__ zr,
                                 double2* __restrict__ zrb) {

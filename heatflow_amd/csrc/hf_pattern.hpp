@@ -30,10 +30,18 @@ struct RowGather {
   ColDict cols;                    // column lists per RBA-row block
 };
 
-struct Pattern {
-  std::vector<int32_t> rowptr, colidx, blk_eptr, blk_cptr, blk_elist;
+// Owner-computes element lists of the LDS scatter kernels (k_assemble_lds, k_grad_rhs): built on demand only,
+// the default path (row gather) does not need them.
+struct OwnerLists {
+  std::vector<int32_t> blk_eptr, blk_cptr, blk_elist;
   std::vector<int2> blk_ent;       // 3 x int2 per list entry: element record + nine slot offsets + ownership mask
-  int max_blk_nnz = 0, ncolors = 0;
+  int ncolors = 0;
+};
+
+struct Pattern {
+  std::vector<int32_t> rowptr, colidx;
+  std::vector<int32_t> nptr, nlist;   // node -> incident elements (ascending), the input of the list builders
+  int max_blk_nnz = 0;
   RowGather rg;
 };
 
@@ -67,8 +75,9 @@ bool build_coldict(const std::vector<int32_t>& rowptr, const std::vector<int32_t
 // Row-gather lists from the node -> element adjacency (nptr / nlist, elements in ascending order per node).
 // Not available (rg.ok = false; the LDS scatter kernels are used instead) when a row holds more than 32 entries,
 // the mesh carries more than 64 distinct cell tags or a block's column list is longer than the kernel prefetches.
-void build_rowgather(int32_t n, int32_t ne, const int32_t* tri, const int32_t* tag, const std::vector<int32_t>& nptr,
-                     const std::vector<int32_t>& nlist, Pattern& P) {
+void build_rowgather(int32_t n, int32_t ne, const int32_t* tri, const int32_t* tag, Pattern& P) {
+  const std::vector<int32_t>& nptr = P.nptr;
+  const std::vector<int32_t>& nlist = P.nlist;
   RowGather& G = P.rg;
   G.ok = false;
   for (int32_t i = 0; i < n; ++i)
@@ -117,11 +126,14 @@ void build_rowgather(int32_t n, int32_t ne, const int32_t* tri, const int32_t* t
   G.ok = true;
 }
 
-int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const int32_t* tag, Pattern& P) {
-  std::vector<int32_t> nptr(static_cast<size_t>(n) + 1, 0);
+// CSR sparsity pattern of the P1 operators + the node -> element adjacency it is built from.
+int build_csr(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, Pattern& P) {
+  std::vector<int32_t>& nptr = P.nptr;
+  std::vector<int32_t>& nlist = P.nlist;
+  nptr.assign(static_cast<size_t>(n) + 1, 0);
   for (int64_t k = 0; k < 3LL * ne; ++k) nptr[tri[k] + 1]++;
   for (int32_t i = 0; i < n; ++i) nptr[i + 1] += nptr[i];
-  std::vector<int32_t> nlist(static_cast<size_t>(3) * ne);
+  nlist.resize(static_cast<size_t>(3) * ne);
   {
     std::vector<int32_t> cur(nptr.begin(), nptr.end() - 1);
     for (int32_t e = 0; e < ne; ++e)
@@ -130,33 +142,43 @@ int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const 
   P.rowptr.assign(static_cast<size_t>(n) + 1, 0);
   P.colidx.clear();
   P.colidx.reserve(static_cast<size_t>(8) * n);
-  std::vector<int32_t> tmp;
+  int32_t tmp[3 * 64];
+  std::vector<int32_t> big;
   for (int32_t i = 0; i < n; ++i) {
-    tmp.clear();
+    const int deg = nptr[i + 1] - nptr[i];
+    if (deg == 0) return fail(ctx, HF_ERR_ARG, "node %d belongs to no triangle", i);
+    int32_t* buf = tmp;
+    if (deg > 64) { big.resize(static_cast<size_t>(3) * deg); buf = big.data(); }
+    int m = 0;
     for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
       const int32_t e = nlist[q];
-      tmp.push_back(tri[3 * e]); tmp.push_back(tri[3 * e + 1]); tmp.push_back(tri[3 * e + 2]);
+      buf[m++] = tri[3 * e]; buf[m++] = tri[3 * e + 1]; buf[m++] = tri[3 * e + 2];
     }
-    if (tmp.empty()) return fail(ctx, HF_ERR_ARG, "node %d belongs to no triangle", i);
-    std::sort(tmp.begin(), tmp.end());
-    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-    P.colidx.insert(P.colidx.end(), tmp.begin(), tmp.end());
+    std::sort(buf, buf + m);
+    m = static_cast<int>(std::unique(buf, buf + m) - buf);
+    P.colidx.insert(P.colidx.end(), buf, buf + m);
     if (P.colidx.size() > static_cast<size_t>(INT32_MAX)) return fail(ctx, HF_ERR_ARG, "nnz exceeds int32");
     P.rowptr[i + 1] = static_cast<int32_t>(P.colidx.size());
   }
-  // owner lists + greedy colouring per row block
+  P.max_blk_nnz = 0;
+  for (int32_t r0 = 0; r0 < n; r0 += RBA) P.max_blk_nnz = std::max(P.max_blk_nnz, P.rowptr[std::min<int32_t>(n, r0 + RBA)] - P.rowptr[r0]);
+  return HF_OK;
+}
+
+// Owner lists + greedy colouring per row block (LDS scatter kernels).
+int build_owner_lists(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const int32_t* tag, const Pattern& P, OwnerLists& O) {
+  const std::vector<int32_t>& nptr = P.nptr;
+  const std::vector<int32_t>& nlist = P.nlist;
   const int nblk = (n + RBA - 1) / RBA;
-  P.blk_eptr.assign(static_cast<size_t>(nblk) + 1, 0);
-  P.blk_cptr.assign(static_cast<size_t>(nblk) * (NCOL + 1), 0);
-  P.blk_elist.clear();
-  P.blk_elist.reserve(static_cast<size_t>(ne) * 3 / 2);
+  O.blk_eptr.assign(static_cast<size_t>(nblk) + 1, 0);
+  O.blk_cptr.assign(static_cast<size_t>(nblk) * (NCOL + 1), 0);
+  O.blk_elist.clear();
+  O.blk_elist.reserve(static_cast<size_t>(ne) * 3 / 2);
   std::vector<int32_t> stamp(ne, -1), list, color;
   std::vector<uint32_t> mask(RBA);
-  P.max_blk_nnz = 0;
-  P.ncolors = 0;
+  O.ncolors = 0;
   for (int b = 0; b < nblk; ++b) {
     const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
-    P.max_blk_nnz = std::max(P.max_blk_nnz, P.rowptr[r1] - P.rowptr[r0]);
     list.clear();
     for (int32_t i = r0; i < r1; ++i)
       for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
@@ -178,29 +200,29 @@ int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const 
       const int c = __builtin_ctz(~used);
       color[k] = c;
       counts[c]++;
-      P.ncolors = std::max(P.ncolors, c + 1);
+      O.ncolors = std::max(O.ncolors, c + 1);
       for (int a = 0; a < 3; ++a) {
         const int32_t v = tri[3 * e + a];
         if (v >= r0 && v < r1) mask[v - r0] |= (1u << c);
       }
     }
-    const int32_t base = static_cast<int32_t>(P.blk_elist.size());
-    int32_t* cp = &P.blk_cptr[static_cast<size_t>(b) * (NCOL + 1)];
+    const int32_t base = static_cast<int32_t>(O.blk_elist.size());
+    int32_t* cp = &O.blk_cptr[static_cast<size_t>(b) * (NCOL + 1)];
     cp[0] = base;
     for (int c = 0; c < NCOL; ++c) cp[c + 1] = cp[c] + counts[c];
-    P.blk_elist.resize(P.blk_elist.size() + list.size());
+    O.blk_elist.resize(O.blk_elist.size() + list.size());
     int32_t cur[NCOL];
     for (int c = 0; c < NCOL; ++c) cur[c] = cp[c];
-    for (size_t k = 0; k < list.size(); ++k) P.blk_elist[cur[color[k]]++] = list[k];
-    P.blk_eptr[b] = base;
-    P.blk_eptr[b + 1] = static_cast<int32_t>(P.blk_elist.size());
+    for (size_t k = 0; k < list.size(); ++k) O.blk_elist[cur[color[k]]++] = list[k];
+    O.blk_eptr[b] = base;
+    O.blk_eptr[b + 1] = static_cast<int32_t>(O.blk_elist.size());
   }
   // widen every list entry with the offsets of its nine contributions inside the CSR rows
-  P.blk_ent.resize(3 * P.blk_elist.size());
+  O.blk_ent.resize(3 * O.blk_elist.size());
   for (int b = 0; b < nblk; ++b) {
     const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
-    for (int32_t q = P.blk_eptr[b]; q < P.blk_eptr[b + 1]; ++q) {
-      const int32_t e = P.blk_elist[q];
+    for (int32_t q = O.blk_eptr[b]; q < O.blk_eptr[b + 1]; ++q) {
+      const int32_t e = O.blk_elist[q];
       const int32_t nd[3] = {tri[3 * e], tri[3 * e + 1], tri[3 * e + 2]};
       uint32_t pos[9] = {0}, owned = 0;
       for (int a = 0; a < 3; ++a) {
@@ -213,13 +235,33 @@ int build_pattern(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, const 
       }
       if (tag[e] >= (1 << 21)) return fail(ctx, HF_ERR_ARG, "cell tag %d does not fit the packed list entry (max 2^21 - 1)", tag[e]);
       const uint32_t w3 = pos[8] | (owned << 8) | (static_cast<uint32_t>(tag[e]) << 11);
-      P.blk_ent[3 * q] = make_int2(nd[0], nd[1]);
-      P.blk_ent[3 * q + 1] = make_int2(nd[2], static_cast<int>(w3));
-      P.blk_ent[3 * q + 2] = make_int2(static_cast<int>(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24)),
+      O.blk_ent[3 * q] = make_int2(nd[0], nd[1]);
+      O.blk_ent[3 * q + 1] = make_int2(nd[2], static_cast<int>(w3));
+      O.blk_ent[3 * q + 2] = make_int2(static_cast<int>(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24)),
                                        static_cast<int>(pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24)));
     }
   }
-  build_rowgather(n, ne, tri, tag, nptr, nlist, P);
+  return HF_OK;
+}
+
+// The lists of the LDS scatter kernels on the device, built from the host copies of the mesh the first time a
+// kernel that needs them is asked for.
+int ensure_owner_lists(hf_ctx* ctx) {
+  if (ctx->owner_ready) return HF_OK;
+  if (ctx->h_tri.empty()) return fail(ctx, HF_ERR_STATE, "element lists requested without a host copy of the mesh");
+  Pattern P;   // adjacency again (cheap next to the colouring), pattern from the context
+  HF_TRY(build_csr(ctx, ctx->n, ctx->ne, ctx->h_tri.data(), P));
+  OwnerLists O;
+  HF_TRY(build_owner_lists(ctx, ctx->n, ctx->ne, ctx->h_tri.data(), ctx->h_tag.data(), P, O));
+  ctx->ncolors = O.ncolors;
+  ctx->elist_len = static_cast<int64_t>(O.blk_elist.size());
+  HF_TRY(dev_alloc(ctx, &ctx->d_blk_eptr, O.blk_eptr.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_blk_cptr, O.blk_cptr.size()));
+  HF_TRY(dev_alloc(ctx, &ctx->d_blk_ent, O.blk_ent.size()));
+  HF_HIP(copy_sync(ctx, ctx->d_blk_eptr, O.blk_eptr.data(), sizeof(int32_t) * O.blk_eptr.size(), hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_blk_cptr, O.blk_cptr.data(), sizeof(int32_t) * O.blk_cptr.size(), hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, ctx->d_blk_ent, O.blk_ent.data(), sizeof(int2) * O.blk_ent.size(), hipMemcpyHostToDevice));
+  ctx->owner_ready = true;
   return HF_OK;
 }
 
@@ -228,6 +270,7 @@ size_t spmv_smem_bytes(const hf_ctx* c) { return static_cast<size_t>(c->max_chun
 // LDS-staged element kernel into (Mout, Aout) with the given coefficient tables.
 int launch_assemble_lds(hf_ctx* ctx, bool colored, const double* kappa_tab, const double* rhoc_tab, double dt,
                         double* Mout, double* Aout) {
+  HF_TRY(ensure_owner_lists(ctx));
   const int cap = (ctx->max_blk_nnz + 1) & ~1;  // keep the int array 8-byte aligned
   const size_t sm = static_cast<size_t>(cap) * 16 + (RBA + 1) * 4;
   if (sm > 64 * 1024) {  // beyond the default dynamic-LDS window: opt in (160 KB per CU on gfx950)

@@ -115,6 +115,17 @@ def prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack):
     return coords, tris, tags, tag_map
 
 
+def build_pattern_blob(coords, tris, tags, device_id=0):
+    """The connectivity-derived tables of a mesh (CSR pattern, compressed column lists, row-gather assembly
+    lists), built ONCE on this GPU and returned as a uint8 array: a sweep hands it to every solver session of
+    every rank (``SimulationSession(..., pattern=blob)``), which then installs instead of rebuilding."""
+    from .hip_backend import HeatflowHIP
+
+    with HeatflowHIP(device_id) as be:
+        be.set_mesh(coords, tris, tags)
+        return be.export_pattern()
+
+
 class SimulationSession:
     """A mesh resident on one GPU, reusable for many runs of the same geometry.
 
@@ -123,7 +134,7 @@ class SimulationSession:
     """
 
     def __init__(self, coords, tris, tags, material_tags, *, device_id=0, backend=None, rtol=DEFAULT_RTOL,
-                 max_it=DEFAULT_MAX_IT, assembly_mode=3, precond=1):
+                 max_it=DEFAULT_MAX_IT, assembly_mode=3, precond=1, pattern=None):
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.tris = np.ascontiguousarray(tris, dtype=np.int32)
         self.tags = np.ascontiguousarray(tags, dtype=np.int32)
@@ -131,6 +142,7 @@ class SimulationSession:
         self.device_id, self.backend = device_id, backend
         self.rtol, self.max_it, self.assembly_mode = rtol, max_it, assembly_mode
         self.precond = precond           # 1 = multigrid-preconditioned CG (default), 0 = Jacobi-PCG
+        self.pattern = pattern           # connectivity tables built once for this mesh (build_pattern_blob), or None
         self.problem = None
         self._key = None
         self._tree = None
@@ -182,7 +194,7 @@ class SimulationSession:
             self.problem = HeatProblem(self.coords, self.tris, self.tags, tag_to_k, tag_to_rc, dt, bcs, ic_temp,
                                        backend=self.backend, device_id=self.device_id, rtol=self.rtol,
                                        max_it=self.max_it, assembly_mode=self.assembly_mode, precond=self.precond,
-                                       amg_reuse=True)
+                                       amg_reuse=True, pattern=self.pattern)
             self._key = key
             self._k = dict(tag_to_k)
             self._k_hier = dict(tag_to_k)            # conductivities the multigrid levels were built for

@@ -20,7 +20,8 @@ PC_JACOBI, PC_AMG = 0, 1
 K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS, K_STREAM_READ = range(7)
 
 EXPORTS = [
-    "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_materials",
+    "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_mesh_prebuilt", "hf_pattern_export_size",
+    "hf_pattern_export", "hf_set_materials",
     "hf_update_kappa", "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_set_start_vector", "hf_get_response_solves", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
     "hf_flux_setup", "hf_flux_project", "hf_flux_solve", "hf_flux_sample", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
@@ -82,6 +83,9 @@ def load_library():
         "hf_create": [C.c_int, C.POINTER(vp)],
         "hf_destroy": [vp],
         "hf_set_mesh": [vp, i32, i32, pd, pi, pi],
+        "hf_set_mesh_prebuilt": [vp, i32, i32, pd, pi, pi, vp, i64],
+        "hf_pattern_export_size": [vp, C.POINTER(i64)],
+        "hf_pattern_export": [vp, vp, i64],
         "hf_set_materials": [vp, i32, pi, pd, pd],
         "hf_update_kappa": [vp, i32, pi, pd],
         "hf_set_dirichlet": [vp, i32, pi],
@@ -177,12 +181,42 @@ class HeatflowHIP:
         raise HipError(rc, msg)
 
     # -- set-up --------------------------------------------------------------------------
-    def set_mesh(self, coords, tris, tags):
+    def set_mesh(self, coords, tris, tags, pattern=None):
+        """``pattern``: the tables another context exported for the same mesh (:meth:`export_pattern`: a uint8
+        array, or ``(address, nbytes)`` of a host or device buffer); they are installed instead of being rebuilt."""
         zr, tri, tag = _f64(coords), _i32(tris), _i32(tags)
         if zr.ndim != 2 or zr.shape[1] != 2 or tri.ndim != 2 or tri.shape[1] != 3 or tag.shape != (tri.shape[0],):
             raise ValueError("set_mesh: coords (n,2), tris (n_e,3), tags (n_e,) expected")
-        self._check(self._lib.hf_set_mesh(self._ctx, zr.shape[0], tri.shape[0], _pd(zr), _pi(tri), _pi(tag)))
+        if pattern is None:
+            self._check(self._lib.hf_set_mesh(self._ctx, zr.shape[0], tri.shape[0], _pd(zr), _pi(tri), _pi(tag)))
+        else:
+            if isinstance(pattern, tuple):
+                addr, nbytes = int(pattern[0]), int(pattern[1])
+            else:
+                pattern = np.ascontiguousarray(pattern, dtype=np.uint8)
+                addr, nbytes = pattern.ctypes.data, pattern.nbytes
+            self._check(self._lib.hf_set_mesh_prebuilt(self._ctx, zr.shape[0], tri.shape[0], _pd(zr), _pi(tri), _pi(tag),
+                                                       C.c_void_p(addr), nbytes))
         self._refresh_sizes()
+
+    def pattern_bytes(self):
+        nb = C.c_int64()
+        self._check(self._lib.hf_pattern_export_size(self._ctx, C.byref(nb)))
+        return int(nb.value)
+
+    def export_pattern(self, into=None):
+        """The connectivity-derived tables of this context's mesh (CSR pattern, compressed column lists, row-gather
+        lists) as one uint8 array, for ``set_mesh(..., pattern=)`` of other contexts.  ``into = (address, nbytes)``
+        writes to that host or device buffer instead and returns None."""
+        nb = self.pattern_bytes()
+        if into is not None:
+            if int(into[1]) != nb:
+                raise ValueError(f"export_pattern: buffer of {into[1]} bytes, need {nb}")
+            self._check(self._lib.hf_pattern_export(self._ctx, C.c_void_p(int(into[0])), nb))
+            return None
+        blob = np.empty(nb, dtype=np.uint8)
+        self._check(self._lib.hf_pattern_export(self._ctx, C.c_void_p(blob.ctypes.data), nb))
+        return blob
 
     def _refresh_sizes(self):
         n, ne, nbc, nnz = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()

@@ -30,7 +30,7 @@ from datetime import datetime
 import numpy as np
 import yaml
 
-from .driver import SimulationSession, prepare_mesh, run_simulation_impl
+from .driver import SimulationSession, build_pattern_blob, prepare_mesh, run_simulation_impl
 from .geometry import build_stack, watcher_points as _watcher_points
 
 
@@ -112,6 +112,50 @@ def broadcast_mesh(arrays, tag_map=None, src=0):
     return tuple(out), box[0]
 
 
+def broadcast_bytes(blob, src=0):
+    """Broadcast a uint8 array (the pattern blob) from ``src``; GPU-to-GPU with nccl, on the host with gloo."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return blob
+    import torch
+
+    on_gpu = d.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    rank = d.get_rank()
+    size = torch.tensor([len(blob) if rank == src else 0], dtype=torch.int64, device=dev)
+    d.broadcast(size, src)
+    t = torch.from_numpy(np.ascontiguousarray(blob, dtype=np.uint8)).to(dev) if rank == src else \
+        torch.empty(int(size[0]), dtype=torch.uint8, device=dev)
+    d.broadcast(t, src)
+    return t.cpu().numpy()
+
+
+def shared_pattern(arrays, device_id, session_factory, pattern_builder, timing=None):
+    """Rank 0 builds the connectivity tables of the mesh once and broadcasts them ("mesh/CSR pattern
+    from rank 0"); every session of every rank installs them.  Without a builder (tests that inject their own
+    session factory and no builder) nothing is shared and each session builds its own."""
+    if pattern_builder is None:
+        if session_factory is not None:
+            return None
+        pattern_builder = build_pattern_blob
+    rank, _ = world_info()
+    t0 = time.perf_counter()
+    blob = pattern_builder(*arrays, device_id) if rank == 0 else np.zeros(0, np.uint8)
+    t1 = time.perf_counter()
+    blob = broadcast_bytes(blob)
+    if timing is not None:
+        timing["pattern_build_s"] = t1 - t0
+        timing["pattern_broadcast_s"] = time.perf_counter() - t1
+        timing["pattern_bytes"] = int(len(blob))
+    return blob
+
+
+def make_session(arrays, tag_map, device_id, session_factory, pattern):
+    if session_factory is not None:
+        return session_factory(*arrays, tag_map) if pattern is None else session_factory(*arrays, tag_map, pattern=pattern)
+    return SimulationSession(*arrays, tag_map, device_id=device_id, pattern=pattern)
+
+
 _EMPTY_MESH = (np.zeros((0, 2)), np.zeros((0, 3), np.int32), np.zeros(0, np.int32))
 
 
@@ -143,7 +187,7 @@ def run_single_simulation(args, session=None, kind=None):
 
 def run_parameter_sweep(base_config_path, output_dir, fwhm_range, k_range, width_range, num_points,
                         base_mesh_folder="meshes", write_xdmf=False, suppress_print=True, num_processes=None, *,
-                        session_factory=None, device_id=None):
+                        session_factory=None, device_id=None, pattern_builder=None):
     """Sweep driver.  ``num_processes`` is accepted for signature parity; the degree of
     parallelism is the size of the torch.distributed world (one rank per GPU).
     ``session_factory(coords, tris, tags, tag_map)`` lets tests substitute the solver session."""
@@ -187,10 +231,8 @@ def run_parameter_sweep(base_config_path, output_dir, fwhm_range, k_range, width
             coords, tris, tags, tag_map = prepare_mesh(cfg0, mesh_folder, not have, stack0)
             arrays = (coords, tris, tags)
         arrays, tag_map = broadcast_mesh(arrays, tag_map)
-        if session_factory is not None:
-            session = session_factory(*arrays, tag_map)
-        else:
-            session = SimulationSession(*arrays, tag_map, device_id=device_id)
+        pattern = shared_pattern(arrays, device_id, session_factory, pattern_builder)
+        session = make_session(arrays, tag_map, device_id, session_factory, pattern)
         try:
             for idx, combo in shard(group, rank, world):
                 row = run_single_simulation((combo, base_config, mesh_folder, output_dir, write_xdmf, suppress_print,
@@ -240,7 +282,7 @@ def get_k_values(k0=3.8, half_width=0.5, step=0.02, count=None):
 
 def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=False, session_factory=None,
                     device_id=None, exp_csv=None, concurrent=1, warmup_steps=0, on_ready=None, on_done=None,
-                    timing=None):
+                    timing=None, pattern_builder=None):
     """k_sample sweep on one mesh: point i -> rank i mod world; the mesh (arrays + tag map) is broadcast
     once, each rank keeps it resident and only re-values A per point.  Returns rows [{k, rmse, runtime,...}]
     (rmse of the normalised o-side watcher against the experiment, sweep_test.py:76-93).
@@ -271,8 +313,8 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
     arrays, tag_map = broadcast_mesh(arrays, tag_map)
     if timing is not None:
         timing["broadcast_s"] = time.perf_counter() - t_phase
-    session = session_factory(*arrays, tag_map) if session_factory else SimulationSession(*arrays, tag_map,
-                                                                                        device_id=device_id)
+    pattern = shared_pattern(arrays, device_id, session_factory, pattern_builder, timing)
+    session = make_session(arrays, tag_map, device_id, session_factory, pattern)
     exp = None
     if exp_csv is not None:
         exp = np.genfromtxt(exp_csv, delimiter=",", names=True)
@@ -307,8 +349,7 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
     try:
         n_sess = min(concurrent, len(mine)) if concurrent > 1 else 1
         for _ in range(max(n_sess, 1) - 1):
-            sessions.append(session_factory(*arrays, tag_map) if session_factory
-                            else SimulationSession(*arrays, tag_map, device_id=device_id))
+            sessions.append(make_session(arrays, tag_map, device_id, session_factory, pattern))
         if warmup_steps > 0 and len(k_values):
             t_phase = time.perf_counter()
             cw = copy.deepcopy(cfg)

@@ -40,13 +40,14 @@ class HeatProblem:
     assembly_mode : ASM_ROW_GATHER (default: a lane per CSR row, no atomics, bitwise reproducible matrices),
               ASM_LDS_COLORED (LDS scatter by colours, reproducible), ASM_LDS_ATOMIC (LDS atomics, diagonals
               summed in arrival order) or ASM_GLOBAL_ATOMIC (baseline)
+    pattern : connectivity tables exported by another context on the same mesh (HeatflowHIP.export_pattern)
     precond : PC_JACOBI (Jacobi-PCG, the north-star solver) or PC_AMG (PCG preconditioned by a
               smoothed-aggregation V-cycle: same stopping rule and answer, ~50x fewer iterations)
     """
 
     def __init__(self, coords, tris, tags, tag_to_k, tag_to_rho_cv, dt, bcs, u0, *, backend=None, device_id=0,
                  assembly_mode=ASM_ROW_GATHER, rtol=DEFAULT_RTOL, atol=0.0, max_it=DEFAULT_MAX_IT,
-                 precond=PC_JACOBI, amg_reuse=False):
+                 precond=PC_JACOBI, amg_reuse=False, pattern=None):
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.n = self.coords.shape[0]
         self.dt = float(dt)
@@ -58,7 +59,11 @@ class HeatProblem:
         self._own_backend = backend is None
 
         t0 = time.perf_counter()
-        self.backend.set_mesh(self.coords, tris, tags)
+        if pattern is None:
+            self.backend.set_mesh(self.coords, tris, tags)
+        else:   # connectivity tables built once elsewhere (another rank / context of the sweep): install, do not rebuild
+            self.backend.set_mesh(self.coords, tris, tags, pattern=pattern)
+        self.mesh_seconds = time.perf_counter() - t0
         self.set_materials(tag_to_k, tag_to_rho_cv, assemble=False)
         if self.bcs:
             self.bc_dofs, self._owner, self._pos = merge_bcs(self.bcs)

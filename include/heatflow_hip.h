@@ -7,6 +7,8 @@
  *
  *   hf_set_mesh        gmshio.model_to_mesh(...)            run_with_diamond.py:240-245
  *                      fem.functionspace(domain, P1 / DG0)  run_with_diamond.py:279-280
+ *   hf_set_mesh_prebuilt / hf_pattern_export   the same for the 2nd..Nth worker of a sweep, which in the
+ *                      reference re-reads mesh.msh and rebuilds everything   parameter_sweep.py:401-446
  *   hf_set_materials   kappa.x.array[:] / rho_cv.x.array[:] run_with_diamond.py:286-301
  *   hf_set_dirichlet   fem.dirichletbc(g, row_dofs) x 4     dirichlet_bc/bc.py:104-113,
  *                                                           run_with_diamond.py:362-374
@@ -90,6 +92,19 @@ const char* hf_last_error(const hf_ctx* ctx);
  * tag = n_e cell tags (>= 0).  Builds the CSR sparsity pattern and the row-block
  * element lists once (host side) and uploads everything. */
 int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t n_e, const double* zr, const int32_t* tri, const int32_t* tag);
+
+/* The tables hf_set_mesh derives from the connectivity (CSR pattern, compressed column lists of the SpMV chunks,
+ * row-gather assembly lists) in serialised form, so that ONE context builds them and every other context on the
+ * same mesh - other ranks of a sweep, further contexts of the same rank - installs them without rebuilding:
+ * the MI355X counterpart of the reference's workers each re-reading mesh.msh (parameter_sweep.py:401-446).
+ * hf_pattern_export writes exactly hf_pattern_export_size bytes; hf_set_mesh_prebuilt = hf_set_mesh with the
+ * tables taken from such a blob (validated against n, n_e and its own index ranges; the mesh arrays themselves
+ * are trusted to be the ones the blob was exported for).  `blob` may be a host or a device pointer in both calls
+ * (hipMemcpyDefault), so an RCCL broadcast buffer can be handed over as it is. */
+int hf_pattern_export_size(hf_ctx* ctx, int64_t* bytes);
+int hf_pattern_export(hf_ctx* ctx, void* blob, int64_t bytes);
+int hf_set_mesh_prebuilt(hf_ctx* ctx, int32_t n, int32_t n_e, const double* zr, const int32_t* tri, const int32_t* tag,
+                         const void* blob, int64_t bytes);
 
 /* Cell-tag -> coefficient tables: kappa[c] = kappa[i], rho_c[c] = rho_c[i] for cells with
  * tag == tags[i].  May be called again (kappa sweep) followed by hf_assemble. */

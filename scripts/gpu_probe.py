@@ -30,7 +30,7 @@ names = {hb.K_SPMV: ("spmv", 12 * nnz + 20 * n), hb.K_PCG_SPMV: ("pcg_spmv", 12 
 for k, (nm, byt) in names.items():
     t = be.time_kernel(k, 200)
     print("  %-11s %8.2f us  %7.1f GB/s (algorithmic %d B)" % (nm, t * 1e3, byt / t / 1e6, byt), flush=True)
-for m in (0, 1, 2):
+for m in (0, 1, 2, 3):
     be.assemble(prob.dt, m)
     t = be.time_kernel(hb.K_ASSEMBLE, 20)
     byt = 16 * ne + 16 * n + 16 * nnz

@@ -14,19 +14,22 @@ def short(name):
     m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", name)
     if not m:
         return name[:30]
-    targs = re.sub(r",\s*(true|false)", "", m.group(2) or "")     # k_spmv<9, true> (compressed columns) -> k_spmv<9>
+    targs = m.group(2) or ""
+    if m.group(1) == "k_spmv":
+        targs = re.sub(r",\s*(true|false)", "", targs)             # k_spmv<9, true> (compressed columns) -> k_spmv<9>
     return m.group(1) + targs
 
 
 res = {}
 for kind, d in (("fetch", fetch_dir), ("write", write_dir)):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"))[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     res[kind] = acc
 alg = {"k_spmv<9>": 12 * nnz + 44 * n, "k_spmv<0>": 12 * nnz + 20 * n, "k_spmv<3>": 12 * nnz + 28 * n,
-       "k_spmv<4>": 12 * nnz + 36 * n, "k_pcg_update_amg": 64 * n, "k_pcg_update": 64 * n, "k_spmv<8>": 12 * nnz + 36 * n, "k_assemble_lds<false>": 16 * ne + 16 * n + 16 * nnz}
+       "k_spmv<4>": 12 * nnz + 36 * n, "k_pcg_update_amg": 64 * n, "k_pcg_update": 64 * n, "k_spmv<8>": 12 * nnz + 36 * n, "k_assemble_lds<false>": 16 * ne + 16 * n + 16 * nnz,
+       "k_assemble_lds<true>": 16 * ne + 16 * n + 16 * nnz, "k_assemble_rows": 16 * ne + 16 * n + 16 * nnz, "k_spmv<2>": 12 * nnz + 36 * n}
 kern = {}
 with open(out + ".csv", "w") as f:
     f.write("kernel,launches,FETCH_SIZE_KB_p90,WRITE_SIZE_KB_p90,hbm_bytes_per_launch_corrected,algorithmic_bytes,ratio\n")

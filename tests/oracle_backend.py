@@ -7,6 +7,14 @@ import scipy.sparse.linalg as spla
 from oracle import heat_oracle as ho
 
 
+def fake_pattern_blob(coords, tris, tags, device_id=0):
+    """What a test passes as ``pattern_builder``: a byte string that depends on the mesh (the real one is
+    HeatflowHIP.export_pattern)."""
+    import hashlib
+    h = hashlib.sha1(np.ascontiguousarray(tris, dtype=np.int32).tobytes() + np.ascontiguousarray(tags, dtype=np.int32).tobytes())
+    return np.frombuffer(b"FAKEPATT" + h.digest(), dtype=np.uint8).copy()
+
+
 class OracleBackend:
     def __init__(self, device_id=0):
         self.n = self.n_e = self.n_bc = 0
@@ -20,7 +28,11 @@ class OracleBackend:
     def close(self):
         self.closed = True
 
-    def set_mesh(self, coords, tris, tags):
+    def set_mesh(self, coords, tris, tags, pattern=None):
+        if pattern is not None:                  # stand-in for hf_set_mesh_prebuilt: the blob must belong to this mesh
+            if not np.array_equal(np.asarray(pattern), fake_pattern_blob(coords, tris, tags)):
+                raise ValueError("pattern blob does not belong to this mesh")
+            self.prebuilt_calls = getattr(self, "prebuilt_calls", 0) + 1
         self.coords = np.asarray(coords, dtype=np.float64)
         self.tris = np.asarray(tris, dtype=np.int64)
         self.tags = np.asarray(tags)

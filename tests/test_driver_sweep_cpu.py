@@ -113,9 +113,9 @@ def test_grid_helpers_match_reference_conventions():
     assert ps.shard(list("abcdefgh"), 1, 3) == [(1, "b"), (4, "e"), (7, "h")]
 
 
-def _session_factory(coords, tris, tags, tag_map):
+def _session_factory(coords, tris, tags, tag_map, pattern=None):
     from heatflow_amd.driver import SimulationSession
-    return SimulationSession(coords, tris, tags, tag_map, backend=OracleBackend())
+    return SimulationSession(coords, tris, tags, tag_map, backend=OracleBackend(), pattern=pattern)
 
 
 def test_sweep_single_process_writes_artefacts_and_failed_rows(tmp_path):
@@ -213,11 +213,20 @@ KAPPA_WORKER = textwrap.dedent("""
     import torch.distributed as dist
     from heatflow_amd import parameter_sweep as ps
     from test_driver_sweep_cpu import _session_factory
+    from oracle_backend import fake_pattern_blob
     dist.init_process_group("gloo")
     cfg = yaml.safe_load(open({cfg!r}))
     timing = {{}}
-    rows = ps.run_kappa_sweep(cfg, {mesh!r}, [3.3, 3.6, 3.9, 4.2], {out!r}, session_factory=_session_factory,
-                              concurrent=2, warmup_steps=2, timing=timing)
+    made = []
+    def factory(*a, **kw):
+        made.append(kw.get("pattern") is not None)
+        return _session_factory(*a, **kw)
+    rows = ps.run_kappa_sweep(cfg, {mesh!r}, [3.3, 3.6, 3.9, 4.2], {out!r}, session_factory=factory,
+                              concurrent=2, warmup_steps=2, timing=timing, pattern_builder=fake_pattern_blob)
+    timing["sessions_with_pattern"] = sum(made)
+    gathered = [None, None]
+    dist.all_gather_object(gathered, timing)
+    timing = {{"rank0": gathered[0], "rank1": gathered[1], **gathered[0]}}
     if dist.get_rank() == 0:
         json.dump({{"rows": rows, "timing": timing}}, open({res!r}, "w"))
     dist.destroy_process_group()
@@ -263,6 +272,9 @@ def test_kappa_sweep_world_size_2_uses_rank0s_tag_map_for_a_cached_mesh(tmp_path
     assert [r["status"] for r in got["rows"]] == ["success"] * 4, got["rows"]
     assert [r["rank"] for r in got["rows"]] == [0, 1, 0, 1]
     assert got["timing"]["sessions"] == 2 and got["timing"]["points_here"] == 2 and got["timing"]["warmup_s"] > 0
+    # the connectivity tables: built by rank 0 only, broadcast, installed by every session of both ranks
+    for r in ("rank0", "rank1"):
+        assert got["timing"][r]["sessions_with_pattern"] == 2 and got["timing"][r]["pattern_bytes"] == 28
     for r in got["rows"]:
         a = np.genfromtxt(os.path.join(str(tmp_path / "out1"), f"{r['k']:.2f}", "watcher_points.csv"), delimiter=",", names=True)
         b = np.genfromtxt(os.path.join(str(tmp_path / "out2"), f"{r['k']:.2f}", "watcher_points.csv"), delimiter=",", names=True)

@@ -870,3 +870,83 @@ def test_mesh_read_through_the_msh41_reader_runs_on_hip_and_matches_the_oracle(h
         assert ref["fields"][-1].max() > 320.0 and max(prob.iters) >= 3
     finally:
         prob.close()
+
+
+def test_pattern_blob_export_and_prebuilt_install(hip, case_with_diamond_small):
+    """hf_pattern_export / hf_set_mesh_prebuilt: the connectivity tables one context built are installed by another
+    (host blob, and a blob held in device memory as an RCCL broadcast leaves it); matrices, lazily built scatter
+    lists and a short time loop are bit-identical to the context that built them.  Damaged blobs are refused."""
+    cfg, stack, mesh = case_with_diamond_small
+    tag_to_k, tag_to_rc = material_tables(stack, mesh)
+    tags = sorted(tag_to_k)
+
+    def matrices(be, mode):
+        be.set_materials(tags, [tag_to_k[t] for t in tags], [tag_to_rc[t] for t in tags])
+        be.assemble(1e-7, mode)
+        return be.get_csr()
+
+    with hip.HeatflowHIP(0) as a:
+        a.set_mesh(mesh.coords, mesh.tris, mesh.tags)
+        blob = a.export_pattern()
+        assert blob.dtype == np.uint8 and blob.nbytes == a.pattern_bytes() and bytes(blob[:6]) == b"HFPAT0"
+        ref = {m: matrices(a, m) for m in (3, 1, 0)}
+    with hip.HeatflowHIP(0) as b:
+        b.set_mesh(mesh.coords, mesh.tris, mesh.tags, pattern=blob)
+        assert (b.n, b.n_e, b.nnz) == (len(mesh.coords), len(mesh.tris), len(ref[3][1]))
+        for m in (3, 1):                                  # mode 1 builds the scatter lists on first use
+            got = matrices(b, m)
+            for x, y in zip(got, ref[m]):
+                assert np.array_equal(x, y)
+        assert np.array_equal(b.export_pattern(), blob)   # and exports the same blob again
+    # a blob in device memory (what an RCCL broadcast leaves behind): plain hipMalloc through the HIP runtime the
+    # library itself uses (torch's bundled runtime cannot be initialised after it in one process)
+    import ctypes as C
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    assert rt.hipMalloc(C.byref(d_in), blob.nbytes) == 0 and rt.hipMalloc(C.byref(d_out), blob.nbytes) == 0
+    try:
+        assert rt.hipMemcpy(d_in, C.c_void_p(blob.ctypes.data), blob.nbytes, 1) == 0          # host -> device
+        with hip.HeatflowHIP(0) as c:
+            c.set_mesh(mesh.coords, mesh.tris, mesh.tags, pattern=(d_in.value, blob.nbytes))
+            got = matrices(c, 3)
+            assert all(np.array_equal(x, y) for x, y in zip(got, ref[3]))
+            c.export_pattern(into=(d_out.value, blob.nbytes))
+        back = np.empty_like(blob)
+        assert rt.hipMemcpy(C.c_void_p(back.ctypes.data), d_out, blob.nbytes, 2) == 0          # device -> host
+        assert np.array_equal(back, blob)
+    finally:
+        rt.hipFree(d_in)
+        rt.hipFree(d_out)
+    # whole problems: built vs installed tables give the same time loop, bit for bit
+    states = []
+    for pat in (None, blob):
+        prob = make_problem(cfg, stack, mesh, precond=1, pattern=pat)
+        try:
+            for bc in prob.bcs:
+                bc.update(0.0)
+            for k in range(8):
+                prob.step((k + 1) * prob.dt, only=[prob.bcs[3]])
+            states.append((prob.state(), list(prob.iters)))
+        finally:
+            prob.close()
+    assert states[0][1] == states[1][1] and np.array_equal(states[0][0], states[1][0])
+    # refused: wrong magic, wrong size, other mesh, an index out of range
+    with hip.HeatflowHIP(0) as d:
+        bad = blob.copy(); bad[0] ^= 1
+        with pytest.raises(ValueError, match="not a pattern blob"):
+            d.set_mesh(mesh.coords, mesh.tris, mesh.tags, pattern=bad)
+        with pytest.raises(ValueError, match="bytes"):
+            d.set_mesh(mesh.coords, mesh.tris, mesh.tags, pattern=blob[:-16])
+        with pytest.raises(ValueError, match="exported for a mesh"):
+            d.set_mesh(mesh.coords[:-1], mesh.tris[mesh.tris.max(axis=1) < len(mesh.coords) - 1], mesh.tags[mesh.tris.max(axis=1) < len(mesh.coords) - 1], pattern=blob)
+        bad = blob.copy()
+        hdr = 8 + 16 + 10 * 4 + 12 * 8
+        off = (hdr + 15) // 16 * 16 + (4 * (len(mesh.coords) + 1) + 15) // 16 * 16     # first column index
+        bad[off:off + 4] = np.frombuffer(np.int32(len(mesh.coords) + 5).tobytes(), dtype=np.uint8)
+        with pytest.raises(ValueError, match="outside its range"):
+            d.set_mesh(mesh.coords, mesh.tris, mesh.tags, pattern=bad)
+        d.set_mesh(mesh.coords, mesh.tris, mesh.tags, pattern=blob)        # the context is still usable
+        assert d.n == len(mesh.coords)
