@@ -17,7 +17,7 @@ refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
   broadcasts over RCCL together with its tag map; no data-path collective.  value = all ranks' DOF-updates /
   max-over-ranks time ("weak" scaling).
 * workload ``sweep64`` (BASELINE C5): 64 kappa_sample values (parameter_sweep.get_k_values(count=64)) at stock
-  mesh size, point i -> rank i mod world, 4 points in flight per rank; K = time steps per point (default: the
+  mesh size, point i -> rank i mod world, 6 points in flight per rank; K = time steps per point (default: the
   config's 100), W = untimed steps every solver session runs first.  value = 64*n*K / wall of the point loop
   (max over ranks), "strong" scaling (the 64 points are fixed).  The same sweep is also run as a side
   measurement of the default workload (``config.sweep64``; ``--sweep-points 0`` skips it).
@@ -53,7 +53,7 @@ TARGET_DOF = 1.0e6
 MESH_SCALE = 0.43          # all `mesh:` values x 0.43 -> 1.04 M nodes (within +-5 % of 1.0e6)
 HBM_SCALE = 0.1075         # -> 16 M nodes: matrix 1.3 GB, vectors 128 MB each, nothing stays in the 256 MiB Infinity Cache
 SWEEP_POINTS = 64          # BASELINE C5
-SWEEP_CONCURRENT = 4       # points in flight per rank (stock-size kernels are latency-bound: profiles/r01_sweep64_one_gpu.json)
+SWEEP_CONCURRENT = 6       # points in flight per rank (stock-size kernels are latency-bound; 1/2/4/6/8/16 in flight: 1.7/3.1/3.9/4.5/4.4/4.2e8 DOF-updates/s)
 
 
 def parse_args(argv=None):
