@@ -10,7 +10,7 @@
 // Reference semantics being reproduced: run_with_diamond.py:321-337 (forms), :381-394 (assemble
 // once, symmetric Dirichlet elimination, solve), :469-481 (loop body).
 
-#include "hf_solver.hpp"
+#include "hf_batch.hpp"
 
 // ==========================================================================================
 // C ABI
@@ -40,6 +40,7 @@ inline size_t pad16(size_t b) { return (b + 15) & ~static_cast<size_t>(15); }
 
 // Upload the tables and size every buffer of the context for the mesh.
 int install_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int32_t* tri, const int32_t* tag, MeshTables& T) {
+  free_batch(ctx);
   ctx->n = n; ctx->ne = ne; ctx->nnz = static_cast<int64_t>(T.colidx.size());
   ctx->nchunks = (n + RB - 1) / RB;
   ctx->nblk_a = (n + RBA - 1) / RBA;
@@ -330,7 +331,7 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_uprev); dev_free(&ctx->d_ustart);
   dev_free(&ctx->d_u); dev_free(&ctx->d_b); dev_free(&ctx->d_r); dev_free(&ctx->d_p); dev_free(&ctx->d_Ap);
-  free_amg(ctx); free_responses(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
+  free_batch(ctx); free_amg(ctx); free_responses(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
   dev_free(&ctx->d_M1); dev_free(&ctx->d_dinv1); dev_free(&ctx->d_gz); dev_free(&ctx->d_gr); dev_free(&ctx->d_bz); dev_free(&ctx->d_br);
   dev_free(&ctx->d_tmp); dev_free(&ctx->d_part_pAp); dev_free(&ctx->d_part_rz); dev_free(&ctx->d_part_zz);
   dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp);
@@ -452,6 +453,7 @@ int hf_set_dirichlet(hf_ctx* ctx, int32_t n_bc, const int32_t* dofs) {
     if (seen[dofs[q]]) return fail(ctx, HF_ERR_ARG, "hf_set_dirichlet: dof %d listed twice (resolve overlaps on the host)", dofs[q]);
     seen[dofs[q]] = 1;
   }
+  free_batch(ctx);
   ctx->nbc = n_bc;
   HF_TRY(dev_alloc(ctx, &ctx->d_bc_dofs, n_bc));
   HF_TRY(dev_alloc(ctx, &ctx->d_g, n_bc));
@@ -503,7 +505,7 @@ int hf_assemble(hf_ctx* ctx, double dt, int32_t mode) {
 int hf_set_precond(hf_ctx* ctx, int32_t kind, int32_t reuse) {
   if (!ctx) return HF_ERR_ARG;
   if (kind < 0 || kind > 1) return fail(ctx, HF_ERR_ARG, "hf_set_precond: unknown preconditioner %d", kind);
-  if (kind != ctx->precond) { ctx->assembled = false; ctx->pred_iters = 0; }
+  if (kind != ctx->precond) { ctx->assembled = false; ctx->pred_iters = 0; (void)hipSetDevice(ctx->dev); free_batch(ctx); }
   if (kind == 0) { (void)hipSetDevice(ctx->dev); free_amg(ctx); }
   ctx->precond = kind;
   ctx->amg_reuse = reuse ? 1 : 0;
@@ -738,6 +740,168 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, doubl
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->last_ms = ms;
   if (ns > 0 && rc == HF_OK) (void)copy_sync(ctx, samples, d_sall, sizeof(double) * n_steps * ns, hipMemcpyDeviceToHost);
+  return rc;
+}
+
+int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t per_column_operator) {
+  if (!ctx) return HF_ERR_ARG;
+  if (!ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_batch_begin before hf_assemble");
+  if (nv != 2 && nv != 4 && nv != 8) return fail(ctx, HF_ERR_ARG, "hf_batch_begin: 2, 4 or 8 columns (got %d)", nv);
+  if (per_column_operator && ctx->precond == 1 && !ctx->amg_reuse)
+    return fail(ctx, HF_ERR_STATE, "hf_batch_begin: per-column operators need the frozen hierarchy (hf_set_precond(1, reuse = 1))");
+  HF_HIP(hipSetDevice(ctx->dev));
+  free_batch(ctx);
+  hf_ctx::Batch& B = ctx->batch;
+  const size_t n = static_cast<size_t>(ctx->n), vec = n * nv;
+  B.percol = per_column_operator != 0;
+  if (B.percol) {
+    HF_TRY(dev_alloc(ctx, &B.A, static_cast<size_t>(ctx->nnz) * nv));
+    HF_TRY(dev_alloc(ctx, &B.dinv, vec));
+    HF_TRY(dev_alloc(ctx, &B.lift_val, static_cast<size_t>(std::max(ctx->nlift, 1)) * nv));
+  }
+  for (double** v : {&B.u, &B.uprev, &B.ustart, &B.b, &B.r, &B.p, &B.Ap, &B.z, &B.z2, &B.tmp}) {
+    HF_TRY(dev_alloc(ctx, v, vec));
+    HF_HIP(hipMemsetAsync(*v, 0, sizeof(double) * vec, ctx->stream));
+  }
+  HF_TRY(dev_alloc(ctx, &B.part_pAp, static_cast<size_t>(nv) * MAXP));
+  HF_TRY(dev_alloc(ctx, &B.part_rz, 2 * static_cast<size_t>(nv) * MAXP));
+  HF_TRY(dev_alloc(ctx, &B.part_zz, static_cast<size_t>(nv) * MAXP));
+  HF_TRY(dev_alloc(ctx, &B.part_bn, static_cast<size_t>(nv) * MAXP));
+  HF_TRY(dev_alloc(ctx, &B.scal, nv));
+  HF_HIP(hipMemsetAsync(B.scal, 0, sizeof(Scal) * nv, ctx->stream));
+  if (hipHostMalloc(reinterpret_cast<void**>(&B.h_scal), sizeof(Scal) * nv) != hipSuccess) return fail(ctx, HF_ERR_ALLOC, "hipHostMalloc failed");
+  const int rpb = TPB / nv;
+  B.Pb = static_cast<int>(std::min<size_t>((n + rpb - 1) / rpb, MAXP));
+  if (B.Pb >= 64) B.Pb &= ~7;
+  if (ctx->precond == 1 && ctx->amg_ready) {   // level vectors, laid out as build_amg lays out the single-column ones
+    const size_t nl = ctx->amg.size();
+    B.lev.resize(nl);
+    for (size_t l = 1; l < nl; ++l) {
+      const DevLevel& L = ctx->amg[l];
+      hf_ctx::BatchLevel& Q = B.lev[l];
+      if (l + 1 < nl) {
+        const size_t len = (static_cast<size_t>(L.n) + L.P.ncol + 2) * nv;
+        HF_TRY(dev_alloc(ctx, &Q.cat, len));
+        HF_HIP(hipMemsetAsync(Q.cat, 0, sizeof(double) * len, ctx->stream));
+        Q.b = Q.cat;
+      } else {
+        HF_TRY(dev_alloc(ctx, &Q.b, (static_cast<size_t>(L.n) + 2) * nv));
+        Q.own_b = true;
+        HF_HIP(hipMemsetAsync(Q.b, 0, sizeof(double) * (static_cast<size_t>(L.n) + 2) * nv, ctx->stream));
+      }
+      if (l == 1) {
+        HF_TRY(dev_alloc(ctx, &Q.x, (static_cast<size_t>(L.n) + 2) * nv));
+        Q.res = Q.x;
+      } else {
+        Q.res = B.lev[l - 1].cat + static_cast<size_t>(ctx->amg[l - 1].n) * nv;
+      }
+    }
+  }
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  B.nv = nv;
+  B.have_prev = false;
+  B.pred_iters = 0;
+  B.loaded = 0;
+  return HF_OK;
+}
+
+int hf_batch_end(hf_ctx* ctx) {
+  if (!ctx) return HF_ERR_ARG;
+  (void)hipSetDevice(ctx->dev);
+  free_batch(ctx);
+  return HF_OK;
+}
+
+int hf_batch_load_column(hf_ctx* ctx, int32_t j) {
+  if (!ctx) return HF_ERR_ARG;
+  hf_ctx::Batch& B = ctx->batch;
+  if (B.nv == 0 || !B.percol) return fail(ctx, HF_ERR_STATE, "hf_batch_load_column: no batch with per-column operators is open");
+  if (!ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_batch_load_column: the context holds no assembled operator");
+  if (j < 0 || j >= B.nv) return fail(ctx, HF_ERR_ARG, "hf_batch_load_column: column %d outside [0,%d)", j, B.nv);
+  HF_HIP(hipSetDevice(ctx->dev));
+  hipLaunchKernelGGL(kb_put_column, dim3(1024), dim3(256), 0, ctx->stream, static_cast<size_t>(ctx->nnz), B.nv, j, ctx->d_A, B.A);
+  hipLaunchKernelGGL(kb_put_column, dim3(1024), dim3(256), 0, ctx->stream, static_cast<size_t>(ctx->n), B.nv, j, ctx->d_dinv, B.dinv);
+  if (ctx->nlift > 0)
+    hipLaunchKernelGGL(kb_put_column, dim3(64), dim3(256), 0, ctx->stream, static_cast<size_t>(ctx->nlift), B.nv, j, ctx->d_lift_val, B.lift_val);
+  HF_HIP(hipGetLastError());
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  B.loaded |= 1u << j;
+  return HF_OK;
+}
+
+int hf_batch_set_state(hf_ctx* ctx, int32_t j, const double* u) {
+  if (!ctx) return HF_ERR_ARG;
+  hf_ctx::Batch& B = ctx->batch;
+  if (B.nv == 0) return fail(ctx, HF_ERR_STATE, "hf_batch_set_state: no batch is open");
+  if (j < 0 || j >= B.nv || !u) return fail(ctx, HF_ERR_ARG, "hf_batch_set_state: bad column or null pointer");
+  HF_HIP(hipSetDevice(ctx->dev));
+  HF_HIP(copy_sync(ctx, ctx->d_tmp, u, sizeof(double) * ctx->n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(kb_put_column, dim3(1024), dim3(256), 0, ctx->stream, static_cast<size_t>(ctx->n), B.nv, j, ctx->d_tmp, B.u);
+  HF_HIP(hipGetLastError());
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  B.have_prev = false;
+  return HF_OK;
+}
+
+int hf_batch_get_state(hf_ctx* ctx, int32_t j, double* u) {
+  if (!ctx) return HF_ERR_ARG;
+  hf_ctx::Batch& B = ctx->batch;
+  if (B.nv == 0) return fail(ctx, HF_ERR_STATE, "hf_batch_get_state: no batch is open");
+  if (j < 0 || j >= B.nv || !u) return fail(ctx, HF_ERR_ARG, "hf_batch_get_state: bad column or null pointer");
+  HF_HIP(hipSetDevice(ctx->dev));
+  hipLaunchKernelGGL(kb_get_column, dim3(1024), dim3(256), 0, ctx->stream, static_cast<size_t>(ctx->n), B.nv, j, B.u, ctx->d_tmp);
+  HF_HIP(hipGetLastError());
+  HF_HIP(copy_sync(ctx, u, ctx->d_tmp, sizeof(double) * ctx->n, hipMemcpyDeviceToHost));
+  return HF_OK;
+}
+
+int hf_batch_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, double atol, int32_t max_it, int32_t ns,
+                 const int32_t* nodes, double* samples, int32_t* iters) {
+  if (!ctx) return HF_ERR_ARG;
+  hf_ctx::Batch& B = ctx->batch;
+  if (B.nv == 0) return fail(ctx, HF_ERR_STATE, "hf_batch_run: no batch is open");
+  if (!ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_batch_run before hf_assemble");
+  if (B.percol && B.loaded != (1u << B.nv) - 1u) return fail(ctx, HF_ERR_STATE, "hf_batch_run: not every column's operator has been loaded");
+  if (n_steps <= 0 || (ctx->nbc > 0 && !g_all) || max_it <= 0 || rtol < 0 || atol < 0) return fail(ctx, HF_ERR_ARG, "hf_batch_run: bad arguments");
+  if (ns < 0 || (ns > 0 && (!nodes || !samples))) return fail(ctx, HF_ERR_ARG, "hf_batch_run: bad sample arguments");
+  for (int32_t q = 0; q < ns; ++q)
+    if (nodes[q] < 0 || nodes[q] >= ctx->n) return fail(ctx, HF_ERR_ARG, "hf_batch_run: node %d outside [0,%d)", nodes[q], ctx->n);
+  HF_HIP(hipSetDevice(ctx->dev));
+  const int nv = B.nv;
+  const size_t gstep = static_cast<size_t>(ctx->nbc) * nv;
+  DevTemp<double> t_sall;
+  if (ctx->nbc > 0) {
+    HF_TRY(dev_alloc(ctx, &B.g, gstep * n_steps));
+    HF_HIP(copy_sync(ctx, B.g, g_all, sizeof(double) * gstep * n_steps, hipMemcpyHostToDevice));
+  }
+  if (ns > 0) {
+    HF_TRY(ensure_samples(ctx, ns));
+    HF_TRY(dev_alloc(ctx, &t_sall.p, static_cast<size_t>(n_steps) * nv * ns));
+    HF_HIP(copy_sync(ctx, ctx->d_samp_idx, nodes, sizeof(int32_t) * ns, hipMemcpyHostToDevice));
+  }
+  int rc = HF_OK;
+  HF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int32_t s = 0; s < n_steps && rc == HF_OK; ++s) {
+    const double* gs = ctx->nbc > 0 ? B.g + gstep * s : nullptr;
+    rc = batch_dispatch(ctx, [&](auto ops) { return decltype(ops)::step(ctx, gs, rtol, atol, max_it); });
+    if (iters)
+      for (int j = 0; j < nv; ++j) iters[static_cast<size_t>(s) * nv + j] = B.h_scal[j].iters;
+    if (ns > 0 && rc == HF_OK) {
+      double* out = t_sall.p + static_cast<size_t>(s) * nv * ns;
+      const int thr = ns * nv;
+      switch (nv) {
+        case 2: hipLaunchKernelGGL((kb_gather<2>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, B.u, out); break;
+        case 4: hipLaunchKernelGGL((kb_gather<4>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, B.u, out); break;
+        default: hipLaunchKernelGGL((kb_gather<8>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, B.u, out); break;
+      }
+    }
+  }
+  (void)hipEventRecord(ctx->ev1, ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->last_ms = ms;
+  if (ns > 0 && rc == HF_OK) (void)copy_sync(ctx, samples, t_sall.p, sizeof(double) * n_steps * nv * ns, hipMemcpyDeviceToHost);
   return rc;
 }
 

@@ -158,6 +158,22 @@ struct hf_ctx {
   int flux_valid = 0;          // components (bit 0 z, bit 1 r) the last projection solved
   double *d_M1 = nullptr, *d_dinv1 = nullptr, *d_gz = nullptr, *d_gr = nullptr, *d_bz = nullptr, *d_br = nullptr;
   int pred_flux[2] = {0, 0};
+  // batched time loop (hf_batch_*, hf_batch.hpp): NV sweep points as interleaved columns
+  struct BatchLevel { double *x = nullptr, *cat = nullptr, *b = nullptr, *res = nullptr; bool own_b = false; };
+  struct Batch {
+    int nv = 0;                  // 0: no batch open
+    bool percol = false;         // true: every column has its own fine operator (kappa sweep), false: all share ctx->d_A
+    double *A = nullptr, *dinv = nullptr, *lift_val = nullptr;            // per-column operator data (percol only)
+    double *g = nullptr;                                                   // boundary values of all steps
+    double *u = nullptr, *uprev = nullptr, *ustart = nullptr, *b = nullptr, *r = nullptr, *p = nullptr, *Ap = nullptr;
+    double *z = nullptr, *z2 = nullptr, *tmp = nullptr;
+    double *part_pAp = nullptr, *part_rz = nullptr, *part_zz = nullptr, *part_bn = nullptr;
+    Scal *scal = nullptr, *h_scal = nullptr;
+    std::vector<BatchLevel> lev;
+    int Pb = 0, pred_iters = 0;
+    bool have_prev = false;
+    unsigned loaded = 0;         // bit j: column j's operator has been loaded (percol)
+  } batch;
   // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;

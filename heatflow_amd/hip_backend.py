@@ -23,6 +23,7 @@ EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_mesh_prebuilt", "hf_pattern_export_size",
     "hf_pattern_export", "hf_set_materials",
     "hf_update_kappa", "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_set_start_vector", "hf_get_response_solves", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
+    "hf_batch_begin", "hf_batch_load_column", "hf_batch_set_state", "hf_batch_get_state", "hf_batch_run", "hf_batch_end",
     "hf_flux_setup", "hf_flux_project", "hf_flux_solve", "hf_flux_sample", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
 
@@ -100,6 +101,12 @@ def load_library():
         "hf_sample": [vp, i32, pi, pd],
         "hf_step": [vp, pd, dbl, dbl, i32, pi, pd],
         "hf_run": [vp, i32, pd, dbl, dbl, i32, i32, pi, pd, pi],
+        "hf_batch_begin": [vp, i32, i32],
+        "hf_batch_load_column": [vp, i32],
+        "hf_batch_set_state": [vp, i32, pd],
+        "hf_batch_get_state": [vp, i32, pd],
+        "hf_batch_run": [vp, i32, pd, dbl, dbl, i32, i32, pi, pd, pi],
+        "hf_batch_end": [vp],
         "hf_flux_setup": [vp],
         "hf_flux_project": [vp, dbl, i32, pd, pd, pi],
         "hf_flux_solve": [vp, i32, dbl, i32, pi],
@@ -307,6 +314,47 @@ class HeatflowHIP:
         self.last_run_iters = iters
         self._check(rc)
         return samples, iters
+
+    # -- batched time loop: nv sweep points as the columns of one multi-vector PCG ------------------
+    def batch_begin(self, nv, per_column_operator=False):
+        self._check(self._lib.hf_batch_begin(self._ctx, int(nv), 1 if per_column_operator else 0))
+        self.batch_nv = int(nv)
+
+    def batch_load_column(self, j):
+        """Copy the context's current (assembled, eliminated) operator into column j of the batch."""
+        self._check(self._lib.hf_batch_load_column(self._ctx, int(j)))
+
+    def batch_set_state(self, j, u):
+        u = _f64(u)
+        if u.shape != (self.n,):
+            raise ValueError(f"batch_set_state: expected {self.n} values")
+        self._check(self._lib.hf_batch_set_state(self._ctx, int(j), _pd(u)))
+
+    def batch_get_state(self, j):
+        u = np.empty(self.n, dtype=np.float64)
+        self._check(self._lib.hf_batch_get_state(self._ctx, int(j), _pd(u)))
+        return u
+
+    def batch_run(self, g_all, rtol=1e-10, atol=0.0, max_it=20000, nodes=None):
+        """g_all: (n_steps, n_bc, nv).  Returns samples (n_steps, nv, n_s) and iters (n_steps, nv)."""
+        g = _f64(g_all)
+        nv = self.batch_nv
+        if g.ndim != 3 or g.shape[1] != self.n_bc or g.shape[2] != nv:
+            raise ValueError(f"batch_run: g_all must be (n_steps, {self.n_bc}, {nv})")
+        nsteps = g.shape[0]
+        idx = _i32(nodes) if nodes is not None and len(nodes) else None
+        ns = 0 if idx is None else len(idx)
+        samples = np.empty((nsteps, nv, ns), dtype=np.float64)
+        iters = np.zeros((nsteps, nv), dtype=np.int32)
+        rc = self._lib.hf_batch_run(self._ctx, nsteps, _pd(g) if self.n_bc else None, rtol, atol, int(max_it), ns, _pi(idx),
+                                    _pd(samples) if ns else None, _pi(iters))
+        self.last_run_iters = iters
+        self._check(rc)
+        return samples, iters
+
+    def batch_end(self):
+        self._check(self._lib.hf_batch_end(self._ctx))
+        self.batch_nv = 0
 
     # -- read-flux projection (run_no_diamond) ----------------------------------------------
     def flux_setup(self):

@@ -164,6 +164,28 @@ int hf_step(hf_ctx* ctx, const double* g_bc, double rtol, double atol, int32_t m
 int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_bc_all, double rtol, double atol, int32_t max_it,
            int32_t n_s, const int32_t* nodes, double* samples, int32_t* iters);
 
+/* Batched time loop: nv = 2, 4 or 8 sweep points of ONE mesh, Dirichlet set and rho_c advance together as the
+ * columns of a multi-vector PCG (reference: the independent runs of the parameter grid, parameter_sweep.py:195-235,
+ * and of the kappa list, sweep_test.py:47-52).  Vectors are stored interleaved on the device, every index and every
+ * shared matrix value is read once for nv products, and each column keeps its own alpha / beta / tolerance /
+ * iteration count / done flag; per column the arithmetic and the stopping rule are hf_step's.
+ *   per_column_operator = 0  all columns share the context's assembled operator (points that differ in their
+ *                            boundary values only: fwhm, heating curve)
+ *   per_column_operator = 1  every column has its own A_hat (kappa sweep): assemble a point's operator in the
+ *                            context as usual (hf_update_kappa), then hf_batch_load_column(j) copies A_hat, D^-1
+ *                            and the lifting values into column j.  The multigrid hierarchy is the frozen one
+ *                            (hf_set_precond(1, reuse = 1)) and is shared by all columns.
+ * hf_batch_begin needs a completed hf_assemble; hf_set_mesh / hf_set_dirichlet / hf_set_precond close the batch.
+ * hf_batch_run: g_bc_all = n_steps x n_bc x nv ([step][bc][column]); samples = n_steps x nv x n_s; iters =
+ * n_steps x nv.  The start vector of every solve is 2 u^n - u^{n-1}.  HF_ERR_NOCONV if any column fails. */
+int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t per_column_operator);
+int hf_batch_load_column(hf_ctx* ctx, int32_t j);
+int hf_batch_set_state(hf_ctx* ctx, int32_t j, const double* u);
+int hf_batch_get_state(hf_ctx* ctx, int32_t j, double* u);
+int hf_batch_run(hf_ctx* ctx, int32_t n_steps, const double* g_bc_all, double rtol, double atol, int32_t max_it,
+                 int32_t n_s, const int32_t* nodes, double* samples, int32_t* iters);
+int hf_batch_end(hf_ctx* ctx);
+
 /* Read-flux projection of run_no_diamond (reference run_no_diamond.py:471-491 set-up, :543-550 per
  * step): grad_smooth = L2 projection of grad(T) onto vector P1 with weight r.  hf_flux_setup
  * assembles the unit-coefficient r-weighted mass matrix on the mesh's pattern (once per mesh);

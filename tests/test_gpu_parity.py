@@ -950,3 +950,100 @@ def test_pattern_blob_export_and_prebuilt_install(hip, case_with_diamond_small):
             d.set_mesh(mesh.coords, mesh.tris, mesh.tags, pattern=bad)
         d.set_mesh(mesh.coords, mesh.tris, mesh.tags, pattern=blob)        # the context is still usable
         assert d.n == len(mesh.coords)
+
+
+@pytest.mark.parametrize("precond", [0, 1])
+@pytest.mark.parametrize("nv", [2, 4, 8])
+def test_batched_time_loop_with_per_column_operators_matches_single_runs_and_oracle(hip, nv, precond, case_with_diamond_small):
+    """hf_batch_*: nv kappa_sample values advance together as interleaved columns (per-column fine operator,
+    shared frozen hierarchy).  Every column must match the oracle's run for its kappa at every step (<= 1e-4 K)
+    and the single-column run of the same context to solver tolerance."""
+    import copy
+    from conftest import HEATING_CSV
+    from oracle import heat_oracle as ho
+
+    cfg, stack, mesh = case_with_diamond_small
+    nsteps = 12
+    ks = [3.3 + 0.14 * j for j in range(nv)]
+    tag_s = mesh.material_tags["p_sample"]
+    prob = make_problem(cfg, stack, mesh, precond=precond, amg_reuse=True)
+    be = prob.backend
+    try:
+        for bc in prob.bcs:
+            bc.update(0.0)
+        g_one = np.array([prob.bc_values((k + 1) * prob.dt, [prob.bcs[3]]) for k in range(nsteps)])      # same boundary values for all
+        tk, trc = material_tables(stack, mesh)
+        singles = []
+        for kap in ks:                                   # reference: one column at a time through hf_run
+            be.update_kappa([tag_s], [kap])
+            prob.set_state(300.0)
+            _, it1 = be.run(g_one, prob.rtol, 0.0, prob.max_it, None)
+            singles.append((prob.state(), it1))
+        be.batch_begin(nv, per_column_operator=True)
+        for j, kap in enumerate(ks):
+            be.update_kappa([tag_s], [kap])
+            be.batch_load_column(j)
+            be.batch_set_state(j, np.full(prob.n, 300.0))
+        g_all = np.repeat(g_one[:, :, None], nv, axis=2)
+        nodes = np.array([0, prob.n // 2, prob.n - 1], dtype=np.int32)
+        fields = []
+        for k in range(nsteps):                          # step by step, so that every field can be checked
+            samples, iters = be.batch_run(g_all[k:k + 1], prob.rtol, 0.0, prob.max_it, nodes)
+            fields.append([be.batch_get_state(j) for j in range(nv)])
+            for j in range(nv):
+                assert np.array_equal(samples[0, j], fields[-1][j][nodes])
+        be.batch_end()
+        for j, kap in enumerate(ks):
+            c = copy.deepcopy(cfg)
+            c["mats"]["p_sample"]["k"] = kap
+            ref = ho.run_reference_algorithm(c, mesh.coords, mesh.tris, mesh.tags, mesh.material_tags, HEATING_CSV,
+                                             num_steps=nsteps, keep_fields=True)
+            worst = max(np.abs(fields[k][j] - ref["fields"][k]).max() for k in range(nsteps))
+            assert worst <= FIELD_TOL_K, f"column {j} (kappa {kap}): worst |dT| = {worst:.3e} K"
+            assert np.abs(fields[-1][j] - singles[j][0]).max() <= 1e-5
+        assert not np.array_equal(fields[-1][0], fields[-1][nv - 1])          # the columns really differ
+    finally:
+        prob.close()
+
+
+@pytest.mark.parametrize("precond", [0, 1])
+def test_batched_time_loop_with_a_shared_operator_matches_single_runs(hip, precond, case_no_diamond_small):
+    """Columns that differ only in their boundary values (four fwhm values of the heated line's Gaussian, as the
+    fwhm axis of parameter_sweep.py:195-235): one shared operator, all steps in one hf_batch_run."""
+    from conftest import HEATING_CSV
+    from heatflow_amd.heating import HeatingCurve
+
+    cfg, stack, mesh = case_no_diamond_small
+    nsteps, nv = 14, 4
+    fwhms = [8e-6, 1.32e-5, 2e-5, 4e-5]
+    prob = make_problem(cfg, stack, mesh, precond=precond)
+    be = prob.backend
+    try:
+        ic = float(cfg["heating"]["ic_temp"])
+        g_cols, singles = [], []
+        nodes = np.array([1, prob.n // 3, prob.n - 2], dtype=np.int32)
+        for f in fwhms:
+            heat = HeatingCurve(HEATING_CSV, ic, f)
+            prob.bcs[3]._value = heat.gaussian
+            for bc in prob.bcs:
+                bc.update(0.0)
+            g = np.array([prob.bc_values((k + 1) * prob.dt, [prob.bcs[3]]) for k in range(nsteps)])
+            g_cols.append(g)
+            prob.set_state(ic)
+            samp, it1 = be.run(g, prob.rtol, 0.0, prob.max_it, nodes)
+            singles.append((prob.state(), samp, it1))
+        be.batch_begin(nv, per_column_operator=False)
+        for j in range(nv):
+            be.batch_set_state(j, np.full(prob.n, ic))
+        samples, iters = be.batch_run(np.stack(g_cols, axis=2), prob.rtol, 0.0, prob.max_it, nodes)
+        for j in range(nv):
+            assert np.abs(be.batch_get_state(j) - singles[j][0]).max() <= 1e-5
+            assert np.abs(samples[:, j, :] - singles[j][1]).max() <= 1e-5
+            assert iters[:, j].max() >= 3 and abs(int(iters[:, j].sum()) - int(singles[j][2].sum())) <= 0.15 * int(singles[j][2].sum()) + nsteps   # the batch starts from 2u^n - u^(n-1) without the boundary-response term
+        assert np.abs(singles[0][0] - singles[3][0]).max() > 1.0
+        be.batch_end()
+        # the context still steps on its own after the batch
+        prob.set_state(ic)
+        be.run(g_cols[1][:3], prob.rtol, 0.0, prob.max_it, None)
+    finally:
+        prob.close()
