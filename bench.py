@@ -17,7 +17,7 @@ refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
   broadcasts over RCCL together with its tag map; no data-path collective.  value = all ranks' DOF-updates /
   max-over-ranks time ("weak" scaling).
 * workload ``sweep64`` (BASELINE C5): 64 kappa_sample values (parameter_sweep.get_k_values(count=64)) at stock
-  mesh size, point i -> rank i mod world, 6 points in flight per rank; K = time steps per point (default: the
+  mesh size, point i -> rank i mod world, batches of 8 points per time loop (hf_batch_*), 4 loops in flight per rank; K = time steps per point (default: the
   config's 100), W = untimed steps every solver session runs first.  value = 64*n*K / wall of the point loop
   (max over ranks), "strong" scaling (the 64 points are fixed).  The same sweep is also run as a side
   measurement of the default workload (``config.sweep64``; ``--sweep-points 0`` skips it).
@@ -53,7 +53,8 @@ TARGET_DOF = 1.0e6
 MESH_SCALE = 0.43          # all `mesh:` values x 0.43 -> 1.04 M nodes (within +-5 % of 1.0e6)
 HBM_SCALE = 0.1075         # -> 16 M nodes: matrix 1.3 GB, vectors 128 MB each, nothing stays in the 256 MiB Infinity Cache
 SWEEP_POINTS = 64          # BASELINE C5
-SWEEP_CONCURRENT = 6       # points in flight per rank (stock-size kernels are latency-bound; 1/2/4/6/8/16 in flight: 1.7/3.1/3.9/4.5/4.4/4.2e8 DOF-updates/s)
+SWEEP_BATCH = 8            # points per batched time loop (hf_batch_*): columns of one multi-vector PCG
+SWEEP_CONCURRENT = 4       # time loops in flight per rank (64 points on one GPU, batch 8: 1/2/4 in flight = 5.3/6.3/6.5e8 DOF-updates/s; unbatched, 6 in flight: 4.5e8)
 
 
 def parse_args(argv=None):
@@ -72,6 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--sweep-points", type=int, default=SWEEP_POINTS,
                     help="c3 workload: also run this many kappa points of the C5 sweep as a side measurement (0 = skip)")
     ap.add_argument("--sweep-concurrent", type=int, default=SWEEP_CONCURRENT)
+    ap.add_argument("--sweep-batch", type=int, default=SWEEP_BATCH,
+                    help="sweep points advanced together by the batched time loop (8, 4, 2; 1 = one run per point)")
     ap.add_argument("--hbm-scale", type=float, default=HBM_SCALE,
                     help="mesh factor of the HBM-resident roofline point (N = 1 only; 0 = skip)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -215,7 +218,7 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def run_sweep64(ranks, n_points, steps_per_point, warmup_steps, concurrent):
+def run_sweep64(ranks, n_points, steps_per_point, warmup_steps, concurrent, batch=1):
     """BASELINE C5: `n_points` kappa_sample values on geballe_with_diamond at stock mesh size, point i ->
     rank i mod world, mesh + tag map broadcast once, `concurrent` points in flight per rank
     (reference parameter_sweep.py:423-446, sweep_test.py:47-115).  Returns the measurement (rank 0) or None."""
@@ -247,7 +250,7 @@ def run_sweep64(ranks, n_points, steps_per_point, warmup_steps, concurrent):
         t_all = time.perf_counter()
         rows = ps.run_kappa_sweep(cfg, os.path.join(tmp, "mesh"), ks, os.path.join(tmp, "out"), rebuild_mesh=True,
                                   device_id=ranks.dev_index, concurrent=concurrent, warmup_steps=warmup_steps,
-                                  on_ready=on_ready, on_done=on_done, timing=timing)
+                                  on_ready=on_ready, on_done=on_done, timing=timing, batch=batch)
         t_all = time.perf_counter() - t_all
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -262,9 +265,10 @@ def run_sweep64(ranks, n_points, steps_per_point, warmup_steps, concurrent):
         n_dof = _stock_dof(yaml.safe_load(f))
     return {
         "workload": (f"{n_points}-point kappa_sample sweep [{ks[0]}..{ks[-1]}] on cfgs/geballe_with_diamond.yaml, stock mesh "
-                     f"(BASELINE C5), point i -> rank i mod {ranks.world}, {concurrent} in flight per rank, "
-                     f"steps 0..{steps_per_point - 1} per point"),
+                     f"(BASELINE C5), point i -> rank i mod {ranks.world}, batches of up to {batch} points per time loop, "
+                     f"{concurrent} loops in flight per rank, steps 0..{steps_per_point - 1} per point"),
         "points": n_points, "n_dof": n_dof, "steps_per_point": steps_per_point, "concurrent_per_rank": concurrent,
+        "batch": batch, "rank0_batches": timing.get("batches"),
         "wall_s": wall, "value": n_points * n_dof * steps_per_point / wall, "unit": "DOF-updates/s",
         "points_per_s": n_points / wall, "pcg_iters_per_step_mean": float(np.mean([r["pcg_iters_mean"] for r in rows])),
         "rank0_phases_s": {k: timing.get(k) for k in ("mesh_s", "broadcast_s", "warmup_s", "points_s")},
@@ -408,7 +412,7 @@ def main(argv=None):
               "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
 
     if args.workload == "sweep64":
-        sw = run_sweep64(ranks, SWEEP_POINTS, args.steps, args.warmup, args.sweep_concurrent)
+        sw = run_sweep64(ranks, SWEEP_POINTS, args.steps, args.warmup, args.sweep_concurrent, args.sweep_batch)
         if rank == 0:
             out = dict(common, metric="DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond", value=sw["value"],
                        ms_per_step=1e3 * sw["wall_s"] / args.steps, scaling="strong",
@@ -494,7 +498,7 @@ def main(argv=None):
     prob.close()
 
     # ---- side measurements: the C5 sweep (every N), the HBM-resident roofline point (N = 1)
-    sweep = run_sweep64(ranks, args.sweep_points, 100, max(1, args.warmup), args.sweep_concurrent) if args.sweep_points > 0 else None
+    sweep = run_sweep64(ranks, args.sweep_points, 100, max(1, args.warmup), args.sweep_concurrent, args.sweep_batch) if args.sweep_points > 0 else None
     hbm = hbm_resident_point(args.hbm_scale, dev_index, 3) if (world == 1 and args.hbm_scale > 0) else None
 
     if rank == 0:

@@ -743,22 +743,28 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, doubl
   return rc;
 }
 
-int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t per_column_operator) {
+int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t operator_kind) {
   if (!ctx) return HF_ERR_ARG;
   if (!ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_batch_begin before hf_assemble");
   if (nv != 2 && nv != 4 && nv != 8) return fail(ctx, HF_ERR_ARG, "hf_batch_begin: 2, 4 or 8 columns (got %d)", nv);
-  if (per_column_operator && ctx->precond == 1 && !ctx->amg_reuse)
+  if (operator_kind < 0 || operator_kind > 2) return fail(ctx, HF_ERR_ARG, "hf_batch_begin: unknown operator kind %d", operator_kind);
+  if (operator_kind == HF_BATCH_PER_COLUMN && ctx->precond == 1 && !ctx->amg_reuse)
     return fail(ctx, HF_ERR_STATE, "hf_batch_begin: per-column operators need the frozen hierarchy (hf_set_precond(1, reuse = 1))");
   HF_HIP(hipSetDevice(ctx->dev));
   free_batch(ctx);
   hf_ctx::Batch& B = ctx->batch;
   const size_t n = static_cast<size_t>(ctx->n), vec = n * nv;
-  B.percol = per_column_operator != 0;
-  if (B.percol) {
+  B.opk = operator_kind;
+  for (double& d : B.delta) d = 0.0;
+  if (B.opk == HF_BATCH_PER_COLUMN) {
     HF_TRY(dev_alloc(ctx, &B.A, static_cast<size_t>(ctx->nnz) * nv));
-    HF_TRY(dev_alloc(ctx, &B.dinv, vec));
     HF_TRY(dev_alloc(ctx, &B.lift_val, static_cast<size_t>(std::max(ctx->nlift, 1)) * nv));
   }
+  if (B.opk == HF_BATCH_AFFINE) {
+    HF_TRY(dev_alloc(ctx, &B.A1, static_cast<size_t>(ctx->nnz)));
+    HF_TRY(dev_alloc(ctx, &B.lift1, static_cast<size_t>(std::max(ctx->nlift, 1))));
+  }
+  if (B.opk != HF_BATCH_SHARED) HF_TRY(dev_alloc(ctx, &B.dinv, vec));
   for (double** v : {&B.u, &B.uprev, &B.ustart, &B.b, &B.r, &B.p, &B.Ap, &B.z, &B.z2, &B.tmp}) {
     HF_TRY(dev_alloc(ctx, v, vec));
     HF_HIP(hipMemsetAsync(*v, 0, sizeof(double) * vec, ctx->stream));
@@ -769,6 +775,8 @@ int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t per_column_operator) {
   HF_TRY(dev_alloc(ctx, &B.part_bn, static_cast<size_t>(nv) * MAXP));
   HF_TRY(dev_alloc(ctx, &B.scal, nv));
   HF_HIP(hipMemsetAsync(B.scal, 0, sizeof(Scal) * nv, ctx->stream));
+  HF_TRY(dev_alloc(ctx, &B.red, 1));
+  HF_HIP(hipMemsetAsync(B.red, 0, sizeof(BRed), ctx->stream));
   if (hipHostMalloc(reinterpret_cast<void**>(&B.h_scal), sizeof(Scal) * nv) != hipSuccess) return fail(ctx, HF_ERR_ALLOC, "hipHostMalloc failed");
   const int rpb = TPB / nv;
   B.Pb = static_cast<int>(std::min<size_t>((n + rpb - 1) / rpb, MAXP));
@@ -815,7 +823,7 @@ int hf_batch_end(hf_ctx* ctx) {
 int hf_batch_load_column(hf_ctx* ctx, int32_t j) {
   if (!ctx) return HF_ERR_ARG;
   hf_ctx::Batch& B = ctx->batch;
-  if (B.nv == 0 || !B.percol) return fail(ctx, HF_ERR_STATE, "hf_batch_load_column: no batch with per-column operators is open");
+  if (B.nv == 0 || B.opk != HF_BATCH_PER_COLUMN) return fail(ctx, HF_ERR_STATE, "hf_batch_load_column: no batch with per-column operators is open");
   if (!ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_batch_load_column: the context holds no assembled operator");
   if (j < 0 || j >= B.nv) return fail(ctx, HF_ERR_ARG, "hf_batch_load_column: column %d outside [0,%d)", j, B.nv);
   HF_HIP(hipSetDevice(ctx->dev));
@@ -826,6 +834,58 @@ int hf_batch_load_column(hf_ctx* ctx, int32_t j) {
   HF_HIP(hipGetLastError());
   HF_HIP(hipStreamSynchronize(ctx->stream));
   B.loaded |= 1u << j;
+  return HF_OK;
+}
+
+int hf_batch_set_affine(hf_ctx* ctx, int32_t n_tags, const int32_t* tags, const double* delta) {
+  if (!ctx) return HF_ERR_ARG;
+  hf_ctx::Batch& B = ctx->batch;
+  if (B.nv == 0 || B.opk != HF_BATCH_AFFINE) return fail(ctx, HF_ERR_STATE, "hf_batch_set_affine: no batch with affine operators is open");
+  if (!ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_batch_set_affine: the context holds no assembled operator");
+  if (n_tags <= 0 || !tags || !delta) return fail(ctx, HF_ERR_ARG, "hf_batch_set_affine: bad arguments");
+  for (int32_t q = 0; q < n_tags; ++q)
+    if (tags[q] < 0 || tags[q] >= ctx->tab_len || !ctx->h_tag_used[tags[q]])
+      return fail(ctx, HF_ERR_ARG, "hf_batch_set_affine: tag %d is not a cell tag of the mesh", tags[q]);
+  HF_HIP(hipSetDevice(ctx->dev));
+  // A1 = dt K with unit conductivity on the listed materials and zero elsewhere (no mass part): the element kernel
+  // with an indicator table; its M output (zero) goes to scratch
+  DevTemp<double> t_k, t_c, t_scratch;
+  const int tab = ctx->rg_ok ? 64 : ctx->tab_len;
+  std::vector<double> ind(tab, 0.0), zeros(tab, 0.0);
+  for (int32_t q = 0; q < n_tags; ++q) {
+    if (ctx->rg_ok) {
+      const auto it = std::lower_bound(ctx->h_rg_tags.begin(), ctx->h_rg_tags.end(), tags[q]);
+      ind[it - ctx->h_rg_tags.begin()] = 1.0;
+    } else {
+      ind[tags[q]] = 1.0;
+    }
+  }
+  HF_TRY(dev_alloc(ctx, &t_k.p, tab));
+  HF_TRY(dev_alloc(ctx, &t_c.p, tab));
+  HF_TRY(dev_alloc(ctx, &t_scratch.p, ctx->nnz));
+  HF_HIP(copy_sync(ctx, t_k.p, ind.data(), sizeof(double) * tab, hipMemcpyHostToDevice));
+  HF_HIP(copy_sync(ctx, t_c.p, zeros.data(), sizeof(double) * tab, hipMemcpyHostToDevice));
+  if (ctx->rg_ok) HF_TRY(launch_assemble_rows(ctx, t_k.p, t_c.p, ctx->dt, t_scratch.p, B.A1));
+  else HF_TRY(launch_assemble_lds(ctx, true, t_k.p, t_c.p, ctx->dt, t_scratch.p, B.A1));
+  // Dirichlet elimination of A1: lifting entries kept aside, Dirichlet rows and columns zero (the unit diagonal is A's)
+  if (ctx->nbc > 0) {
+    if (ctx->nlift > 0)
+      hipLaunchKernelGGL(k_zero_slots, dim3((ctx->nlift + 255) / 256), dim3(256), 0, ctx->stream, ctx->nlift, ctx->d_lift_slot, B.A1, B.lift1);
+    hipLaunchKernelGGL(k_zero_rows, dim3((ctx->nbc + 255) / 256), dim3(256), 0, ctx->stream, ctx->nbc, ctx->d_bc_dofs, ctx->d_rowptr, B.A1);
+  }
+  for (int j = 0; j < B.nv; ++j) B.delta[j] = delta[j];
+  BOp op{};
+  op.v0 = ctx->d_A; op.v1 = B.A1;
+  for (int j = 0; j < 8; ++j) op.delta[j] = B.delta[j];
+  const int thr = ctx->n * B.nv;
+  switch (B.nv) {
+    case 2: hipLaunchKernelGGL((kb_affine_dinv<2>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, ctx->d_rowptr, ctx->d_colidx, op, B.dinv); break;
+    case 4: hipLaunchKernelGGL((kb_affine_dinv<4>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, ctx->d_rowptr, ctx->d_colidx, op, B.dinv); break;
+    default: hipLaunchKernelGGL((kb_affine_dinv<8>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, ctx->d_rowptr, ctx->d_colidx, op, B.dinv); break;
+  }
+  HF_HIP(hipGetLastError());
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  B.loaded = 1;
   return HF_OK;
 }
 
@@ -861,7 +921,8 @@ int hf_batch_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol,
   hf_ctx::Batch& B = ctx->batch;
   if (B.nv == 0) return fail(ctx, HF_ERR_STATE, "hf_batch_run: no batch is open");
   if (!ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_batch_run before hf_assemble");
-  if (B.percol && B.loaded != (1u << B.nv) - 1u) return fail(ctx, HF_ERR_STATE, "hf_batch_run: not every column's operator has been loaded");
+  if (B.opk == HF_BATCH_PER_COLUMN && B.loaded != (1u << B.nv) - 1u) return fail(ctx, HF_ERR_STATE, "hf_batch_run: not every column's operator has been loaded");
+  if (B.opk == HF_BATCH_AFFINE && B.loaded == 0) return fail(ctx, HF_ERR_STATE, "hf_batch_run: hf_batch_set_affine has not been called");
   if (n_steps <= 0 || (ctx->nbc > 0 && !g_all) || max_it <= 0 || rtol < 0 || atol < 0) return fail(ctx, HF_ERR_ARG, "hf_batch_run: bad arguments");
   if (ns < 0 || (ns > 0 && (!nodes || !samples))) return fail(ctx, HF_ERR_ARG, "hf_batch_run: bad sample arguments");
   for (int32_t q = 0; q < ns; ++q)

@@ -34,20 +34,72 @@ __device__ __forceinline__ double block_colsum(double v, double* sw /* [4 * NV] 
   return t;
 }
 
+// Sum of a column's P per-workgroup partials (P <= MAXP): TPB / NV threads serve the column, each adds its entries
+// in a fixed order; the loads are issued together (predicated), not one round trip after the other.
 template <int NV>
 __device__ __forceinline__ double col_partials(const double* __restrict__ part /* column's MAXP slots */, int P, double* sw) {
+  constexpr int STRIDE = TPB / NV, NL = (MAXP + STRIDE - 1) / STRIDE;
   double v = 0.0;
-  for (int k = threadIdx.x / NV; k < P; k += TPB / NV) v += part[k];
+#pragma unroll
+  for (int u0 = 0; u0 < NL; u0 += 8) {
+    double e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = threadIdx.x / NV + (u0 + u) * STRIDE;
+      e[u] = (u0 + u < NL && k < P) ? part[k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += e[u];
+  }
   return block_colsum<NV>(v, sw);
 }
 
+// The per-column scalars (BRed) are reduced ONCE per producer by kb_reduce (one small workgroup) instead of by every
+// workgroup of every consumer: with NV columns the partial arrays are NV times larger than in the single-column
+// loop, and re-reading them in each of ~1000 consumer workgroups would cost as much as the matrix.
+
+// one workgroup per (array, column): 256 threads add the column's P partials in a fixed order
+__global__ __launch_bounds__(TPB) void kb_reduce(int P, int nv, const double* __restrict__ part_a, double* __restrict__ out_a,
+                                                 const double* __restrict__ part_b, double* __restrict__ out_b) {
+  __shared__ double s4[4];
+  const int j = blockIdx.x % nv;
+  const bool second = blockIdx.x >= nv;
+  const double* part = (second ? part_b : part_a) + static_cast<size_t>(j) * MAXP;
+  double e[MAXP / TPB];
+#pragma unroll
+  for (int u = 0; u < MAXP / TPB; ++u) {
+    const int k = threadIdx.x + u * TPB;
+    e[u] = k < P ? part[k] : 0.0;
+  }
+  double v = 0.0;
+#pragma unroll
+  for (int u = 0; u < MAXP / TPB; ++u) v += e[u];
+  const double t = block_sum(v, s4);
+  if (threadIdx.x == 0) (second ? out_b : out_a)[j] = t;
+}
+
+// The fine operator of column j of a batch:
+//   OP_SHARED  A_j = A            one value per nonzero (points that differ in their boundary values only)
+//   OP_PERCOL  A_j arbitrary      values interleaved like the vectors, v[k * NV + j]
+//   OP_AFFINE  A_j = A + d_j A1   two shared value arrays and one scalar per column: a sweep over the conductivity of
+//                                 one material (or of materials that move together), A1 = dt K restricted to it
+enum { OP_SHARED = 0, OP_PERCOL = 1, OP_AFFINE = 2 };
+struct BOp { const double* v0; const double* v1; double delta[8]; };
+
+template <int OPK, int NV>
+__device__ __forceinline__ double op_value(const BOp& op, size_t k, int j) {
+  if (OPK == OP_PERCOL) return op.v0[k * NV + j];
+  if (OPK == OP_AFFINE) return op.v0[k] + op.delta[j] * op.v1[k];
+  return op.v0[k];
+}
+
 // Fine-pattern SpMV on NV interleaved columns, thread = (row, column).  Modes as k_spmv (0, 2, 3, 4, 5, 8, 9).
-template <int MODE, int NV, bool PERCOL>
+template <int MODE, int NV, int OPK>
 __global__ __launch_bounds__(TPB) void kb_spmv(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                               const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y,
+                                               const BOp op, const double* __restrict__ x, double* __restrict__ y,
                                                Scal* __restrict__ scal, double* __restrict__ part0, const double* __restrict__ bvec,
                                                const double* __restrict__ dinv, double* __restrict__ pvec, double* __restrict__ part1,
-                                               double* __restrict__ part2, double w, int P, int parity) {
+                                               double* __restrict__ part2, double w, const BRed* __restrict__ red, int parity) {
   __shared__ double sw[4 * NV];
   constexpr int RPB = TPB / NV;
   const int j = threadIdx.x % NV, rl = threadIdx.x / NV;
@@ -58,9 +110,7 @@ __global__ __launch_bounds__(TPB) void kb_spmv(int n, const int32_t* __restrict_
   bool first9 = false;
   if (MODE == 9) {
     first9 = sc->first != 0;
-    const double rz_new = col_partials<NV>(part1 + (parity * NV + j) * MAXP, P, sw);
-    const double rz_old = col_partials<NV>(part1 + ((parity ^ 1) * NV + j) * MAXP, P, sw);
-    const double zz = col_partials<NV>(part2 + j * MAXP, P, sw);
+    const double rz_new = red->rz[parity][j], rz_old = red->rz[parity ^ 1][j], zz = red->zz[j];
     if (active && !first9) {
       const bool conv = zz <= sc->tol2;
       if (blockIdx.x == 0 && rl == 0) {
@@ -80,7 +130,7 @@ __global__ __launch_bounds__(TPB) void kb_spmv(int n, const int32_t* __restrict_
     const size_t o = static_cast<size_t>(row) * NV + j;
     double e_b = 0.0, e_d = 0.0, e_y = 0.0, e_p = 0.0, e_x = 0.0;
     if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 8) e_b = bvec[o];
-    if (MODE == 2 || MODE == 4 || MODE == 5) e_d = PERCOL ? dinv[o] : dinv[row];
+    if (MODE == 2 || MODE == 4 || MODE == 5) e_d = OPK != OP_SHARED ? dinv[o] : dinv[row];
     if (MODE == 9 && !first9) { e_y = y[o]; e_p = pvec[o]; }
     if (MODE == 4 || MODE == 8 || MODE == 9) e_x = x[o];
     double s = 0.0;
@@ -91,7 +141,7 @@ __global__ __launch_bounds__(TPB) void kb_spmv(int n, const int32_t* __restrict_
       for (int u = 0; u < 4; ++u) {
         const bool in = k + u < k1;
         c[u] = in ? colidx[k + u] : 0;
-        v[u] = in ? (PERCOL ? vals[static_cast<size_t>(k + u) * NV + j] : vals[k + u]) : 0.0;
+        v[u] = in ? op_value<OPK, NV>(op, static_cast<size_t>(k + u), j) : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) xv[u] = (k + u < k1) ? x[static_cast<size_t>(c[u]) * NV + j] : 0.0;
@@ -214,14 +264,18 @@ __global__ __launch_bounds__(TPB) void kb_scale(int n, double w, const double* _
     x[q] = w * dinv[q / NV] * b[q];
 }
 
-// PCG start per column: tolerance and convergence of the initial iterate (one workgroup).
+// PCG start per column: tolerance and convergence of the initial iterate (one workgroup); also reduces the start
+// kernel's partial sums (Jacobi: r.z into slot 0).
 template <int NV>
 __global__ __launch_bounds__(TPB) void kb_begin(int P, double rtol, double atol, const double* __restrict__ part_zz,
-                                                const double* __restrict__ part_bn, Scal* __restrict__ scal) {
+                                                const double* __restrict__ part_bn, const double* __restrict__ part_rz0,
+                                                Scal* __restrict__ scal, BRed* __restrict__ red) {
   __shared__ double sw[4 * NV];
   const int j = threadIdx.x % NV;
   const double zz = col_partials<NV>(part_zz + j * MAXP, P, sw);
   const double bn2 = col_partials<NV>(part_bn + j * MAXP, P, sw);
+  double rz0 = 0.0;
+  if (part_rz0 != nullptr) rz0 = col_partials<NV>(part_rz0 + j * MAXP, P, sw);
   if (threadIdx.x < NV) {
     const double tol = fmax(rtol * sqrt(bn2), atol);
     Scal* sc = scal + j;
@@ -231,12 +285,15 @@ __global__ __launch_bounds__(TPB) void kb_begin(int P, double rtol, double atol,
     sc->iters = 0;
     sc->first = 1;
     sc->done = (zz <= tol * tol) ? 1 : 0;
+    red->zz[j] = zz;
+    red->bn[j] = bn2;
+    if (part_rz0 != nullptr) red->rz[0][j] = rz0;
   }
 }
 
 // x += alpha p; r -= alpha Ap; z = D^-1 r (Jacobi: + r.z partials) or z0 = w D^-1 r (multigrid); (D^-1 r)^2 partials
-template <int NV, bool AMG, bool PERCOL>
-__global__ __launch_bounds__(TPB) void kb_update(int n, int P, int parity, Scal* __restrict__ scal, const double* __restrict__ part_pAp,
+template <int NV, bool AMG, bool DINV_PERCOL>
+__global__ __launch_bounds__(TPB) void kb_update(int n, const BRed* __restrict__ red, int parity, Scal* __restrict__ scal,
                                                  double* __restrict__ part_rz, double* __restrict__ part_zz, double* __restrict__ x,
                                                  double* __restrict__ r, const double* __restrict__ p, const double* __restrict__ Ap,
                                                  const double* __restrict__ dinv, double w, double* __restrict__ z) {
@@ -244,8 +301,7 @@ __global__ __launch_bounds__(TPB) void kb_update(int n, int P, int parity, Scal*
   constexpr int RPB = TPB / NV;
   const int j = threadIdx.x % NV, rl = threadIdx.x / NV;
   Scal* sc = scal + j;
-  const double pAp = col_partials<NV>(part_pAp + j * MAXP, P, sw);
-  const double rz = col_partials<NV>(part_rz + (parity * NV + j) * MAXP, P, sw);
+  const double pAp = red->pAp[j], rz = red->rz[parity][j];
   bool active = sc->done == 0;
   if (active && !(pAp > 0.0)) {                          // breakdown (only on NaN / a non-SPD preconditioner)
     if (blockIdx.x == 0 && rl == 0) sc->done = 2;
@@ -260,7 +316,7 @@ __global__ __launch_bounds__(TPB) void kb_update(int n, int P, int parity, Scal*
     if (row >= n || !active) continue;
     const size_t o = static_cast<size_t>(row) * NV + j;
     const double ri = r[o] - alpha * Ap[o];
-    const double zi = (PERCOL ? dinv[o] : dinv[row]) * ri;
+    const double zi = (DINV_PERCOL ? dinv[o] : dinv[row]) * ri;
     x[o] += alpha * p[o];
     r[o] = ri;
     z[o] = AMG ? w * zi : zi;
@@ -276,15 +332,41 @@ __global__ __launch_bounds__(TPB) void kb_update(int n, int P, int parity, Scal*
 }
 
 // b[row, j] -= sum_q lift_val[q, j] * g[lift_bc[q], j]; thread = (lifted row, column)
-template <int NV, bool PERCOL>
+template <int NV, int OPK>
 __global__ void kb_lift(int nrows, const int32_t* __restrict__ rows, const int32_t* __restrict__ ptr, const int32_t* __restrict__ bc,
-                        const double* __restrict__ val, const double* __restrict__ g, double* __restrict__ b) {
+                        const BOp val, const double* __restrict__ g, double* __restrict__ b) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int q = t / NV, j = t % NV;
   if (q >= nrows) return;
   double s = 0.0;
-  for (int k = ptr[q]; k < ptr[q + 1]; ++k) s += (PERCOL ? val[static_cast<size_t>(k) * NV + j] : val[k]) * g[static_cast<size_t>(bc[k]) * NV + j];
+  for (int k = ptr[q]; k < ptr[q + 1]; ++k) s += op_value<OPK, NV>(val, static_cast<size_t>(k), j) * g[static_cast<size_t>(bc[k]) * NV + j];
   b[static_cast<size_t>(rows[q]) * NV + j] -= s;
+}
+
+// affine operators: D^-1 of every column, dinv[i, j] = 1 / (A_ii + d_j A1_ii)
+template <int NV>
+__global__ void kb_affine_dinv(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const BOp op,
+                               double* __restrict__ dinv) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = t / NV, j = t % NV;
+  if (row >= n) return;
+  double d = 0.0;
+  for (int k = rowptr[row]; k < rowptr[row + 1]; ++k)
+    if (colidx[k] == row) d = op_value<OP_AFFINE, NV>(op, static_cast<size_t>(k), j);
+  dinv[static_cast<size_t>(row) * NV + j] = 1.0 / d;
+}
+
+// the part of the operator that scales with the swept conductivity, Dirichlet rows and columns removed
+__global__ void k_zero_slots(int nq, const int32_t* __restrict__ slot, double* __restrict__ A, double* __restrict__ keep) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  if (keep) keep[q] = A[slot[q]];
+  A[slot[q]] = 0.0;
+}
+__global__ void k_zero_rows(int nbc, const int32_t* __restrict__ dofs, const int32_t* __restrict__ rowptr, double* __restrict__ A) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nbc) return;
+  for (int k = rowptr[dofs[q]]; k < rowptr[dofs[q] + 1]; ++k) A[k] = 0.0;
 }
 
 template <int NV>
@@ -320,10 +402,10 @@ __global__ void kb_get_column(size_t n, int nv, int j, const double* __restrict_
 // ------------------------------------------------------------------------------------------
 void free_batch(hf_ctx* ctx) {
   hf_ctx::Batch& B = ctx->batch;
-  dev_free(&B.A); dev_free(&B.dinv); dev_free(&B.lift_val); dev_free(&B.g);
+  dev_free(&B.A); dev_free(&B.A1); dev_free(&B.dinv); dev_free(&B.lift_val); dev_free(&B.lift1); dev_free(&B.g);
   dev_free(&B.u); dev_free(&B.uprev); dev_free(&B.ustart); dev_free(&B.b); dev_free(&B.r); dev_free(&B.p); dev_free(&B.Ap);
   dev_free(&B.z); dev_free(&B.z2); dev_free(&B.tmp);
-  dev_free(&B.part_pAp); dev_free(&B.part_rz); dev_free(&B.part_zz); dev_free(&B.part_bn); dev_free(&B.scal);
+  dev_free(&B.part_pAp); dev_free(&B.part_rz); dev_free(&B.part_zz); dev_free(&B.part_bn); dev_free(&B.scal); dev_free(&B.red);
   for (auto& L : B.lev) { dev_free(&L.x); dev_free(&L.cat); if (L.own_b) dev_free(&L.b); }
   B.lev.clear();
   if (B.h_scal) { (void)hipHostFree(B.h_scal); B.h_scal = nullptr; }
@@ -348,22 +430,46 @@ void blaunch_csr(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
 #undef HF_BCSR
 }
 
-template <int NV, bool PERCOL>
+template <int NV, int OPK>
 struct BatchOps {
-  static const double* Avals(hf_ctx* c) { return PERCOL ? c->batch.A : c->d_A; }
-  static const double* Dinv(hf_ctx* c) { return PERCOL ? c->batch.dinv : c->d_dinv; }
+  static constexpr bool DPC = OPK != OP_SHARED;       // D^-1 stored per column
+  static BOp Aop(hf_ctx* c) {
+    const hf_ctx::Batch& B = c->batch;
+    BOp o{};
+    o.v0 = OPK == OP_PERCOL ? B.A : c->d_A;
+    o.v1 = B.A1;
+    for (int j = 0; j < 8; ++j) o.delta[j] = B.delta[j];
+    return o;
+  }
+  static BOp Liftop(hf_ctx* c) {
+    const hf_ctx::Batch& B = c->batch;
+    BOp o{};
+    o.v0 = OPK == OP_PERCOL ? B.lift_val : c->d_lift_val;
+    o.v1 = B.lift1;
+    for (int j = 0; j < 8; ++j) o.delta[j] = B.delta[j];
+    return o;
+  }
+  static const double* Avals(hf_ctx* c) { return c->d_A; }   // tag: "the system operator" (any pointer but d_M)
+  static const double* Dinv(hf_ctx* c) { return DPC ? c->batch.dinv : c->d_dinv; }
 
   template <int MODE>
   static void spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr, const double* bvec = nullptr,
                    double* pvec = nullptr, double* part1 = nullptr, double* part2 = nullptr, double w = 0.0, int parity = 0) {
     hf_ctx::Batch& B = c->batch;
     // M is always shared (rho_c does not change inside a batch): MODE 0 / 8 on M use the shared-value kernel
-    if (vals == c->d_M)
-      hipLaunchKernelGGL((kb_spmv<MODE, NV, false>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, c->d_rowptr, c->d_colidx, vals, x, y,
-                         B.scal, part0, bvec, c->d_dinv, pvec, part1, part2, w, B.Pb, parity);
-    else
-      hipLaunchKernelGGL((kb_spmv<MODE, NV, PERCOL>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, c->d_rowptr, c->d_colidx, vals, x, y,
-                         B.scal, part0, bvec, Dinv(c), pvec, part1, part2, w, B.Pb, parity);
+    if (vals == c->d_M) {
+      BOp m{};
+      m.v0 = c->d_M;
+      hipLaunchKernelGGL((kb_spmv<MODE, NV, OP_SHARED>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, c->d_rowptr, c->d_colidx, m, x, y,
+                         B.scal, part0, bvec, c->d_dinv, pvec, part1, part2, w, B.red, parity);
+    } else {
+      hipLaunchKernelGGL((kb_spmv<MODE, NV, OPK>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, c->d_rowptr, c->d_colidx, Aop(c), x, y,
+                         B.scal, part0, bvec, Dinv(c), pvec, part1, part2, w, B.red, parity);
+    }
+  }
+
+  static void reduce(hf_ctx* c, const double* part_a, double* out_a, const double* part_b = nullptr, double* out_b = nullptr) {
+    hipLaunchKernelGGL(kb_reduce, dim3(part_b ? 2 * NV : NV), dim3(TPB), 0, c->stream, c->batch.Pb, NV, part_a, out_a, part_b, out_b);
   }
 
   // z = B r for every column: the V(1,1) cycle of hf_solver.hpp's vcycle() on interleaved vectors
@@ -374,6 +480,7 @@ struct BatchOps {
     double* rz_out = B.part_rz + static_cast<size_t>(out_slot) * NV * MAXP;
     if (nl == 1) {
       spmv<4>(c, Avals(c), B.z, B.z2, rz_out, B.r, nullptr, nullptr, nullptr, w0);
+      reduce(c, rz_out, B.red->rz[out_slot], B.part_zz, B.red->zz);
       return;
     }
     spmv<3>(c, Avals(c), B.z, B.tmp, nullptr, B.r);
@@ -393,19 +500,23 @@ struct BatchOps {
     for (int l = nl - 2; l >= 1; --l) blaunch_csr<NV, 0>(c, c->amg[l].GP, B.lev[l].cat, B.lev[l].res);
     blaunch_csr<NV, 1>(c, c->amg[0].P, B.lev[1].res, B.z);
     spmv<4>(c, Avals(c), B.z, B.z2, rz_out, B.r, nullptr, nullptr, nullptr, w0);
+    reduce(c, rz_out, B.red->rz[out_slot], B.part_zz, B.red->zz);   // r.z of this cycle and (D^-1 r)^2 of the last update
   }
 
   static void iteration(hf_ctx* c, bool use_amg, int parity) {
     hf_ctx::Batch& B = c->batch;
     if (use_amg) {
       spmv<9>(c, Avals(c), B.z2, B.Ap, B.part_pAp, nullptr, B.p, B.part_rz, B.part_zz, 0.0, parity);
-      hipLaunchKernelGGL((kb_update<NV, true, PERCOL>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, B.Pb, parity, B.scal, B.part_pAp,
+      reduce(c, B.part_pAp, B.red->pAp);
+      hipLaunchKernelGGL((kb_update<NV, true, DPC>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, B.red, parity, B.scal,
                          B.part_rz, B.part_zz, B.u, B.r, B.p, B.Ap, Dinv(c), c->amg[0].omega, B.z);
       vcycle(c, parity ^ 1);
     } else {
       spmv<9>(c, Avals(c), B.z, B.Ap, B.part_pAp, nullptr, B.p, B.part_rz, B.part_zz, 0.0, parity);
-      hipLaunchKernelGGL((kb_update<NV, false, PERCOL>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, B.Pb, parity, B.scal, B.part_pAp,
+      reduce(c, B.part_pAp, B.red->pAp);
+      hipLaunchKernelGGL((kb_update<NV, false, DPC>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, B.red, parity, B.scal,
                          B.part_rz, B.part_zz, B.u, B.r, B.p, B.Ap, Dinv(c), 0.0, B.z);
+      reduce(c, B.part_rz + static_cast<size_t>(parity ^ 1) * NV * MAXP, B.red->rz[parity ^ 1], B.part_zz, B.red->zz);
     }
   }
 
@@ -428,10 +539,11 @@ struct BatchOps {
     HF_HIP(hipMemsetAsync(B.scal, 0, sizeof(Scal) * NV, ctx->stream));
     if (!use_amg) {
       spmv<2>(ctx, Avals(ctx), B.u, B.r, B.part_rz, B.b, B.z, B.part_zz, B.part_bn, 0.0);
-      hipLaunchKernelGGL((kb_begin<NV>), dim3(1), dim3(TPB), 0, ctx->stream, B.Pb, rtol, atol, B.part_zz, B.part_bn, B.scal);
+      hipLaunchKernelGGL((kb_begin<NV>), dim3(1), dim3(TPB), 0, ctx->stream, B.Pb, rtol, atol, B.part_zz, B.part_bn, B.part_rz, B.scal, B.red);
     } else {
       spmv<5>(ctx, Avals(ctx), B.u, B.r, nullptr, B.b, B.z, B.part_zz, B.part_bn, ctx->amg[0].omega);
-      hipLaunchKernelGGL((kb_begin<NV>), dim3(1), dim3(TPB), 0, ctx->stream, B.Pb, rtol, atol, B.part_zz, B.part_bn, B.scal);
+      hipLaunchKernelGGL((kb_begin<NV>), dim3(1), dim3(TPB), 0, ctx->stream, B.Pb, rtol, atol, B.part_zz, B.part_bn,
+                         static_cast<const double*>(nullptr), B.scal, B.red);
       vcycle(ctx, 0);
     }
     HF_HIP(hipGetLastError());
@@ -473,8 +585,8 @@ struct BatchOps {
     if (nb > 0) {
       if (ctx->nlift_rows > 0) {
         const int thr = ctx->nlift_rows * NV;
-        hipLaunchKernelGGL((kb_lift<NV, PERCOL>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->nlift_rows, ctx->d_lift_rows,
-                           ctx->d_lift_ptr, ctx->d_lift_bc, PERCOL ? B.lift_val : ctx->d_lift_val, g_dev, B.b);
+        hipLaunchKernelGGL((kb_lift<NV, OPK>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->nlift_rows, ctx->d_lift_rows,
+                           ctx->d_lift_ptr, ctx->d_lift_bc, Liftop(ctx), g_dev, B.b);
       }
       hipLaunchKernelGGL((kb_set_bc<NV>), dim3((nb * NV + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, g_dev, B.b, B.u);
     }
@@ -487,13 +599,16 @@ struct BatchOps {
 template <typename F>
 int batch_dispatch(hf_ctx* ctx, F&& f) {
   const hf_ctx::Batch& B = ctx->batch;
-  switch (B.nv * 2 + (B.percol ? 1 : 0)) {
-    case 4: return f(BatchOps<2, false>());
-    case 5: return f(BatchOps<2, true>());
-    case 8: return f(BatchOps<4, false>());
-    case 9: return f(BatchOps<4, true>());
-    case 16: return f(BatchOps<8, false>());
-    case 17: return f(BatchOps<8, true>());
+  switch (B.nv * 4 + B.opk) {
+    case 8: return f(BatchOps<2, OP_SHARED>());
+    case 9: return f(BatchOps<2, OP_PERCOL>());
+    case 10: return f(BatchOps<2, OP_AFFINE>());
+    case 16: return f(BatchOps<4, OP_SHARED>());
+    case 17: return f(BatchOps<4, OP_PERCOL>());
+    case 18: return f(BatchOps<4, OP_AFFINE>());
+    case 32: return f(BatchOps<8, OP_SHARED>());
+    case 33: return f(BatchOps<8, OP_PERCOL>());
+    case 34: return f(BatchOps<8, OP_AFFINE>());
     default: return fail(ctx, HF_ERR_STATE, "no batch is open (hf_batch_begin)");
   }
 }

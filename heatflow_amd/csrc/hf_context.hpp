@@ -46,6 +46,9 @@ struct Scal {                  // device-resident PCG scalars
   int first;                   // 1 until the first update of a solve: the first direction is p = z (beta = 0)
 };
 
+// Per-column scalars of the batched PCG (hf_batch.hpp), each reduced once per producer by a one-workgroup kernel
+struct BRed { double pAp[8], rz[2][8], zz[8], bn[8]; };
+
 }  // namespace
 
 struct hf_ctx {
@@ -162,13 +165,16 @@ struct hf_ctx {
   struct BatchLevel { double *x = nullptr, *cat = nullptr, *b = nullptr, *res = nullptr; bool own_b = false; };
   struct Batch {
     int nv = 0;                  // 0: no batch open
-    bool percol = false;         // true: every column has its own fine operator (kappa sweep), false: all share ctx->d_A
-    double *A = nullptr, *dinv = nullptr, *lift_val = nullptr;            // per-column operator data (percol only)
+    int opk = 0;                 // fine operator of the columns: 0 shared (ctx->d_A), 1 one per column, 2 affine A + d_j A1
+    double *A = nullptr, *dinv = nullptr, *lift_val = nullptr;            // per-column operator data (opk 1; dinv also opk 2)
+    double *A1 = nullptr, *lift1 = nullptr;                               // affine part and its lifting values (opk 2)
+    double delta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double *g = nullptr;                                                   // boundary values of all steps
     double *u = nullptr, *uprev = nullptr, *ustart = nullptr, *b = nullptr, *r = nullptr, *p = nullptr, *Ap = nullptr;
     double *z = nullptr, *z2 = nullptr, *tmp = nullptr;
     double *part_pAp = nullptr, *part_rz = nullptr, *part_zz = nullptr, *part_bn = nullptr;
     Scal *scal = nullptr, *h_scal = nullptr;
+    BRed* red = nullptr;         // per-column reduced scalars
     std::vector<BatchLevel> lev;
     int Pb = 0, pred_iters = 0;
     bool have_prev = false;

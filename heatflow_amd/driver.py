@@ -157,17 +157,10 @@ class SimulationSession:
         tag_to_rc = {self.material_tags[m.name]: m.properties["rho_cv"] for m in stack.materials}
         return tag_to_k, tag_to_rc
 
-    def run(self, cfg, stack, watcher_points=None, field_sink=None, read_flux=False, two_sided=False):
-        """One simulation (reference loop run_with_diamond.py:456-504).  Returns a dict with
-        ``times``, ``watchers`` {name: array}, ``iters``, timing numbers.  ``read_flux`` adds the
-        per-step gradient projection of run_no_diamond.py:543-566 (``flux`` entry of the result)."""
-        t_start = time.time()
-        t_final = float(cfg["timing"]["t_final"])
-        num_steps = int(cfg["timing"]["num_steps"])
-        dt = t_final / num_steps
+    def _boundary_conditions(self, cfg, stack, two_sided=False):
+        """[left, right, top, heated line(s)] of one configuration (reference run_with_diamond.py:343-374)."""
         ic_temp = float(cfg["heating"]["ic_temp"])
         heat = HeatingCurve(_resolve(cfg["heating"]["file"]), ic_temp, float(cfg["heating"]["fwhm"]))
-
         V = P1Space(self.coords)
         bcs = [
             RowDirichletBC(V, "left", value=ic_temp),
@@ -183,11 +176,15 @@ class SimulationSession:
             heat_o = HeatingCurve(_resolve(cfg["heating"]["file"]), ic_temp, float(cfg["heating"]["fwhm"]), column="oside")
             bcs.append(RowDirichletBC(V, "x", coord=stack.heated_z_oside, length=abs(stack.r_sample) * 2, center=0.0,
                                       value=heat_o.gaussian))
-        varying = bcs[3:]
-        tag_to_k, tag_to_rc = self._tables(stack)
+        return bcs
+
+    def _problem_key(self, dt, tag_to_rc, bcs):
         # the resident problem is reusable only for exactly the same Dirichlet DOF sets, in the same order
-        key = (dt, tuple(sorted(tag_to_rc.items())),
-               tuple(hashlib.sha1(np.ascontiguousarray(b.row_dofs, dtype=np.int64).tobytes()).hexdigest() for b in bcs))
+        return (dt, tuple(sorted(tag_to_rc.items())),
+                tuple(hashlib.sha1(np.ascontiguousarray(b.row_dofs, dtype=np.int64).tobytes()).hexdigest() for b in bcs))
+
+    def _ensure_problem(self, key, tag_to_k, tag_to_rc, dt, bcs, ic_temp):
+        """The resident HeatProblem for ``key`` (built if absent), its operator valued for ``tag_to_k``."""
         if self.problem is None or key != self._key:
             self.close()
             print("Assigning material properties...")
@@ -199,33 +196,126 @@ class SimulationSession:
             self._k = dict(tag_to_k)
             self._k_hier = dict(tag_to_k)            # conductivities the multigrid levels were built for
             print("Material properties assigned.")
+            return
+        self.problem.bcs = bcs
+        if tag_to_k != self._k:
+            self._revalue(tag_to_k, tag_to_rc)
+
+    def _revalue(self, tag_to_k, tag_to_rc, allow_rebuild=True):
+        # re-value A on the resident pattern; the frozen coarse levels stay a good preconditioner
+        # while no conductivity moved by more than 2x from the values they were built for
+        # (measured: 3.8 -> 60 W/m/K triples the iteration count), beyond that rebuild them
+        drift = max(max(tag_to_k[t] / self._k_hier[t], self._k_hier[t] / tag_to_k[t]) for t in tag_to_k)
+        if drift > 2.0 and self.precond == 1 and allow_rebuild:
+            self.problem.backend.set_precond(1, False)
+            self.problem.set_materials(tag_to_k, tag_to_rc)
+            self.problem.backend.set_precond(1, True)
+            self._k_hier = dict(tag_to_k)
         else:
-            self.problem.bcs = bcs
-            if tag_to_k != self._k:
-                # re-value A on the resident pattern; the frozen coarse levels stay a good preconditioner
-                # while no conductivity moved by more than 2x from the values they were built for
-                # (measured: 3.8 -> 60 W/m/K triples the iteration count), beyond that rebuild them
-                drift = max(max(tag_to_k[t] / self._k_hier[t], self._k_hier[t] / tag_to_k[t]) for t in tag_to_k)
-                if drift > 2.0 and self.precond == 1:
-                    self.problem.backend.set_precond(1, False)
-                    self.problem.set_materials(tag_to_k, tag_to_rc)
-                    self.problem.backend.set_precond(1, True)
-                    self._k_hier = dict(tag_to_k)
-                else:
-                    self.problem.set_materials(tag_to_k, tag_to_rc)
-                self._k = dict(tag_to_k)
+            self.problem.set_materials(tag_to_k, tag_to_rc)
+        self._k = dict(tag_to_k)
+
+    def _watcher_nodes(self, watcher_points):
+        names, coords_w = _parse_watchers(watcher_points)
+        if not names:
+            return names, None
+        if self._tree is None:                      # nearest-node lookup structure: once per resident mesh
+            from scipy.spatial import cKDTree
+            self._tree = cKDTree(self.coords)
+        return names, np.array([self._tree.query(p)[1] for p in coords_w], dtype=np.int32)
+
+    def run_batch(self, cfgs, stacks, watcher_points=None):
+        """``len(cfgs)`` in (2, 4, 8) simulations of this mesh advanced together (hf_batch_*): the points of a
+        sweep that share geometry, time stepping and rho_c; they may differ in the boundary values (fwhm,
+        heating curve: one shared operator) and in the conductivities (one operator per column, shared
+        frozen multigrid hierarchy).  Returns one result dict per configuration, as :meth:`run` does."""
+        nv = len(cfgs)
+        if nv not in (2, 4, 8):
+            raise ValueError("run_batch: 2, 4 or 8 configurations at a time")
+        t_start = time.time()
+        cfg0 = cfgs[0]
+        num_steps = int(cfg0["timing"]["num_steps"])
+        dt = float(cfg0["timing"]["t_final"]) / num_steps
+        ic_temp = float(cfg0["heating"]["ic_temp"])
+        cols = []
+        for cfg, stack in zip(cfgs, stacks):
+            bcs = self._boundary_conditions(cfg, stack)
+            tk, trc = self._tables(stack)
+            key = self._problem_key(float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"]), trc, bcs)
+            cols.append((bcs, tk, trc, key))
+            if int(cfg["timing"]["num_steps"]) != num_steps or float(cfg["heating"]["ic_temp"]) != ic_temp or key != cols[0][3]:
+                raise ValueError("run_batch: the configurations must share time stepping, ic_temp, rho_c and the Dirichlet sets")
+        percol = any(c[1] != cols[0][1] for c in cols)
+        mid = cols[nv // 2]
+        # conductivities that differ between the columns; a single one (sweep_test.py's kappa_sample list) makes
+        # the operators an affine family A + (kappa_j - kappa_ref) A1: two shared matrices instead of nv
+        varying = [t for t in mid[1] if any(c[1][t] != mid[1][t] for c in cols)]
+        affine = percol and len(varying) == 1
+        self._ensure_problem(mid[3], mid[1], mid[2], dt, mid[0], ic_temp)
+        prob = self.problem
+        be = prob.backend
+        if percol and self.precond == 1:             # all columns share the hierarchy: keep every column within its range
+            worst = max(max(max(c[1][t] / self._k_hier[t], self._k_hier[t] / c[1][t]) for t in c[1]) for c in cols)
+            if worst > 2.0:
+                be.set_precond(1, False)
+                prob.set_materials(mid[1], mid[2])
+                be.set_precond(1, True)
+                self._k_hier, self._k = dict(mid[1]), dict(mid[1])
+        times = (np.arange(num_steps) + 1) * dt
+        g_all = np.empty((num_steps, len(prob.bc_dofs), nv), dtype=np.float64)
+        for j, (bcs, _, _, _) in enumerate(cols):
+            prob.bcs = bcs
+            for bc in bcs:
+                bc.update(0.0)
+            for k, t in enumerate(times):
+                g_all[k, :, j] = prob.bc_values(t, bcs[3:])
+        names, nodes = self._watcher_nodes(watcher_points)
+        if affine and mid[1] != self._k:
+            self._revalue(mid[1], mid[2], allow_rebuild=False)     # the context's operator is the reference of the family
+        be.batch_begin(nv, per_column_operator=2 if affine else (1 if percol else 0))
+        try:
+            if affine:
+                be.batch_set_affine(varying, [c[1][varying[0]] - mid[1][varying[0]] for c in cols])
+            elif percol:
+                for j, (_, tk, trc, _) in enumerate(cols):
+                    if tk != self._k:
+                        self._revalue(tk, trc, allow_rebuild=False)
+                    be.batch_load_column(j)
+            for j in range(nv):
+                be.batch_set_state(j, np.full(prob.n, ic_temp))
+            print("Beginning loop...")
+            t_loop = time.time()
+            samples, iters = be.batch_run(g_all, self.rtol, 0.0, self.max_it, nodes)
+            loop_time = time.time() - t_loop
+        finally:
+            be.batch_end()
+        print(f"Simulation progress: 100% (step {num_steps}/{num_steps}) | {nv} runs together | Avg time/step: "
+              f"{loop_time / num_steps:.4f} s | PCG iterations/step: mean {np.mean(iters):.0f}, max {int(np.max(iters))}")
+        return [{"times": times.copy(), "watcher_names": names,
+                 "watchers": {nm: samples[:, j, k].copy() for k, nm in enumerate(names)},
+                 "iters": iters[:, j].copy(), "loop_time": loop_time / nv, "startup_time": (t_loop - t_start) / nv,
+                 "n_dof": prob.n, "dt": dt, "flux": None, "batch": nv} for j in range(nv)]
+
+    def run(self, cfg, stack, watcher_points=None, field_sink=None, read_flux=False, two_sided=False):
+        """One simulation (reference loop run_with_diamond.py:456-504).  Returns a dict with
+        ``times``, ``watchers`` {name: array}, ``iters``, timing numbers.  ``read_flux`` adds the
+        per-step gradient projection of run_no_diamond.py:543-566 (``flux`` entry of the result)."""
+        t_start = time.time()
+        t_final = float(cfg["timing"]["t_final"])
+        num_steps = int(cfg["timing"]["num_steps"])
+        dt = t_final / num_steps
+        ic_temp = float(cfg["heating"]["ic_temp"])
+        bcs = self._boundary_conditions(cfg, stack, two_sided)
+        varying = bcs[3:]
+        tag_to_k, tag_to_rc = self._tables(stack)
+        key = self._problem_key(dt, tag_to_rc, bcs)
+        fresh = self.problem is None or key != self._key
+        self._ensure_problem(key, tag_to_k, tag_to_rc, dt, bcs, ic_temp)
+        if not fresh:
             self.problem.set_state(ic_temp)
             self.problem.iters = []
         prob = self.problem
-
-        names, coords_w = _parse_watchers(watcher_points)
-        if names:
-            if self._tree is None:                      # nearest-node lookup structure: once per resident mesh
-                from scipy.spatial import cKDTree
-                self._tree = cKDTree(self.coords)
-            nodes = np.array([self._tree.query(p)[1] for p in coords_w], dtype=np.int32)
-        else:
-            nodes = None
+        names, nodes = self._watcher_nodes(watcher_points)
 
         flux = FluxSampler(self.coords) if read_flux else None
         if flux is not None and not getattr(prob, "_flux_ready", False):
@@ -431,6 +521,28 @@ def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_me
         result["save_folder"] = save_folder
         result["total_time"] = total
         return result
+
+
+def run_simulation_batch_impl(kind, cfgs, output_folders, watcher_points_list, session, suppress_print=True):
+    """``run_simulation`` for 2, 4 or 8 configurations of one resident mesh at once (SimulationSession.run_batch):
+    the same per-run artefacts (``used_config.yaml``, ``watcher_points.csv``) in each output folder, no XDMF,
+    no read-flux projection.  Returns the list of result dicts."""
+    with suppress_output(suppress_print):
+        t0 = time.time()
+        stacks = [stack_with_diamond(c) if kind == "with_diamond" else stack_no_diamond(c) for c in cfgs]
+        for wp in watcher_points_list:
+            _parse_watchers(wp)
+        for cfg, folder in zip(cfgs, output_folders):
+            os.makedirs(folder, exist_ok=True)
+            with open(os.path.join(folder, "used_config.yaml"), "w") as f:
+                yaml.safe_dump(cfg, f)
+        results = session.run_batch(cfgs, stacks, watcher_points_list[0])
+        for res, folder, wp in zip(results, output_folders, watcher_points_list):
+            if wp is not None:
+                write_watcher_csv(os.path.join(folder, "watcher_points.csv"), res["times"], res["watcher_names"], res["watchers"])
+            res["save_folder"] = folder
+            res["total_time"] = (time.time() - t0) / len(cfgs)
+        return results
 
 
 def cli(kind, argv=None):

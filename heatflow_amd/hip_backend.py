@@ -18,12 +18,13 @@ HF_OK, HF_ERR_ARG, HF_ERR_STATE, HF_ERR_HIP, HF_ERR_NOCONV, HF_ERR_ALLOC = 0, -1
 ASM_LDS_ATOMIC, ASM_LDS_COLORED, ASM_GLOBAL_ATOMIC, ASM_ROW_GATHER = 0, 1, 2, 3
 PC_JACOBI, PC_AMG = 0, 1
 K_SPMV, K_PCG_SPMV, K_PCG_UPDATE, K_PCG_DIR, K_ASSEMBLE, K_RHS, K_STREAM_READ = range(7)
+BATCH_SHARED, BATCH_PER_COLUMN, BATCH_AFFINE = 0, 1, 2
 
 EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_mesh_prebuilt", "hf_pattern_export_size",
     "hf_pattern_export", "hf_set_materials",
     "hf_update_kappa", "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_set_start_vector", "hf_get_response_solves", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
-    "hf_batch_begin", "hf_batch_load_column", "hf_batch_set_state", "hf_batch_get_state", "hf_batch_run", "hf_batch_end",
+    "hf_batch_begin", "hf_batch_load_column", "hf_batch_set_affine", "hf_batch_set_state", "hf_batch_get_state", "hf_batch_run", "hf_batch_end",
     "hf_flux_setup", "hf_flux_project", "hf_flux_solve", "hf_flux_sample", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
 
@@ -103,6 +104,7 @@ def load_library():
         "hf_run": [vp, i32, pd, dbl, dbl, i32, i32, pi, pd, pi],
         "hf_batch_begin": [vp, i32, i32],
         "hf_batch_load_column": [vp, i32],
+        "hf_batch_set_affine": [vp, i32, pi, pd],
         "hf_batch_set_state": [vp, i32, pd],
         "hf_batch_get_state": [vp, i32, pd],
         "hf_batch_run": [vp, i32, pd, dbl, dbl, i32, i32, pi, pd, pi],
@@ -317,8 +319,16 @@ class HeatflowHIP:
 
     # -- batched time loop: nv sweep points as the columns of one multi-vector PCG ------------------
     def batch_begin(self, nv, per_column_operator=False):
-        self._check(self._lib.hf_batch_begin(self._ctx, int(nv), 1 if per_column_operator else 0))
+        """``per_column_operator``: BATCH_SHARED (False), BATCH_PER_COLUMN (True) or BATCH_AFFINE."""
+        self._check(self._lib.hf_batch_begin(self._ctx, int(nv), int(per_column_operator)))
         self.batch_nv = int(nv)
+
+    def batch_set_affine(self, tags, delta):
+        """Operators A_j = A + delta[j] * dt K(unit conductivity on the cell tags ``tags``), A = the context's operator."""
+        t, d = _i32(tags), _f64(delta)
+        if d.shape != (self.batch_nv,):
+            raise ValueError(f"batch_set_affine: {self.batch_nv} deltas expected")
+        self._check(self._lib.hf_batch_set_affine(self._ctx, len(t), _pi(t), _pd(d)))
 
     def batch_load_column(self, j):
         """Copy the context's current (assembled, eliminated) operator into column j of the batch."""

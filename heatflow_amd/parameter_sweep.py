@@ -30,7 +30,7 @@ from datetime import datetime
 import numpy as np
 import yaml
 
-from .driver import SimulationSession, build_pattern_blob, prepare_mesh, run_simulation_impl
+from .driver import SimulationSession, build_pattern_blob, prepare_mesh, run_simulation_batch_impl, run_simulation_impl
 from .geometry import build_stack, watcher_points as _watcher_points
 
 
@@ -159,6 +159,19 @@ def make_session(arrays, tag_map, device_id, session_factory, pattern):
 _EMPTY_MESH = (np.zeros((0, 2)), np.zeros((0, 3), np.int32), np.zeros(0, np.int32))
 
 
+def batch_groups(items, batch):
+    """Split ``items`` into consecutive groups of 8, 4 or 2 (at most ``batch``) and singles: the group sizes the
+    batched time loop takes (hf_batch_begin)."""
+    out, i = [], 0
+    sizes = [s for s in (8, 4, 2) if s <= max(int(batch), 1)]
+    while i < len(items):
+        left = len(items) - i
+        take = next((s for s in sizes if s <= left), 1)
+        out.append(items[i:i + take])
+        i += take
+    return out
+
+
 def shard(items, rank, world):
     """Round-robin shard: item i -> rank i mod world (8 points per GPU for 64 points on 8 GPUs)."""
     return [(i, it) for i, it in enumerate(items) if i % world == rank]
@@ -185,12 +198,43 @@ def run_single_simulation(args, session=None, kind=None):
     return row
 
 
+def run_simulation_group(items, base_config, mesh_folder, output_dir, write_xdmf, suppress_print, session, kind):
+    """``items`` = [(run_id, combo), ...]: two or more points advance together through the batched time loop
+    (same status rows as run_single_simulation); if the batch fails as a whole, or XDMF / read-flux output is
+    wanted, every point is run on its own instead."""
+    def singly():
+        return [run_single_simulation((combo, base_config, mesh_folder, output_dir, write_xdmf, suppress_print, run_id),
+                                      session=session, kind=kind) for run_id, combo in items]
+
+    if len(items) == 1 or write_xdmf or kind == "no_diamond":     # run_no_diamond's per-step flux projection is not batched
+        return singly()
+    rows, cfgs, folders = [], [], []
+    for run_id, combo in items:
+        fwhm, k, width = combo["fwhm"], combo["k"], combo["width"]
+        name = run_name_for(fwhm, k, width)
+        folders.append(os.path.join(output_dir, name))
+        cfgs.append(modify_config_for_parameters(base_config, fwhm, k, width))
+        rows.append({"run_id": run_id, "run_name": name, "fwhm": fwhm, "k": k, "width": width, "output_dir": folders[-1],
+                     "runtime": 0.0, "status": "failed", "error": None})
+    try:
+        t0 = time.time()
+        results = run_simulation_batch_impl(kind, cfgs, folders, [get_watcher_points(c) for c in cfgs], session, suppress_print)
+        for row, res in zip(rows, results):
+            row.update(runtime=(time.time() - t0) / len(items), status="success", pcg_iters_mean=float(np.mean(res["iters"])),
+                       pcg_iters_max=int(np.max(res["iters"])), batch=len(items))
+        return rows
+    except Exception:
+        return singly()
+
+
 def run_parameter_sweep(base_config_path, output_dir, fwhm_range, k_range, width_range, num_points,
                         base_mesh_folder="meshes", write_xdmf=False, suppress_print=True, num_processes=None, *,
-                        session_factory=None, device_id=None, pattern_builder=None):
+                        session_factory=None, device_id=None, pattern_builder=None, batch=1):
     """Sweep driver.  ``num_processes`` is accepted for signature parity; the degree of
     parallelism is the size of the torch.distributed world (one rank per GPU).
-    ``session_factory(coords, tris, tags, tag_map)`` lets tests substitute the solver session."""
+    ``session_factory(coords, tris, tags, tag_map)`` lets tests substitute the solver session.
+    ``batch`` > 1: up to that many (8, 4 or 2) consecutive points of a rank advance together through the batched
+    time loop (points that share k share one operator, others get one operator per column)."""
     rank, world = world_info()
     with open(base_config_path) as f:
         base_config = yaml.safe_load(f)
@@ -234,11 +278,12 @@ def run_parameter_sweep(base_config_path, output_dir, fwhm_range, k_range, width
         pattern = shared_pattern(arrays, device_id, session_factory, pattern_builder)
         session = make_session(arrays, tag_map, device_id, session_factory, pattern)
         try:
-            for idx, combo in shard(group, rank, world):
-                row = run_single_simulation((combo, base_config, mesh_folder, output_dir, write_xdmf, suppress_print,
-                                             done + idx + 1), session=session, kind=stack0.kind)
-                row["rank"] = rank
-                rows.append(row)
+            mine = [(done + idx + 1, combo) for idx, combo in shard(group, rank, world)]
+            for items in batch_groups(mine, batch):
+                for row in run_simulation_group(items, base_config, mesh_folder, output_dir, write_xdmf, suppress_print,
+                                                session, stack0.kind):
+                    row["rank"] = rank
+                    rows.append(row)
         finally:
             session.close()
         done += len(group)
@@ -282,12 +327,15 @@ def get_k_values(k0=3.8, half_width=0.5, step=0.02, count=None):
 
 def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=False, session_factory=None,
                     device_id=None, exp_csv=None, concurrent=1, warmup_steps=0, on_ready=None, on_done=None,
-                    timing=None, pattern_builder=None):
+                    timing=None, pattern_builder=None, batch=1):
     """k_sample sweep on one mesh: point i -> rank i mod world; the mesh (arrays + tag map) is broadcast
     once, each rank keeps it resident and only re-values A per point.  Returns rows [{k, rmse, runtime,...}]
     (rmse of the normalised o-side watcher against the experiment, sweep_test.py:76-93).
 
-    ``concurrent`` > 1 runs that many of a rank's points at once, each on its own solver context
+    ``batch`` > 1 advances up to that many (8, 4 or 2) of a rank's points together through the batched time loop
+    (hf_batch_*: one operator per column, shared frozen multigrid hierarchy): at stock mesh sizes a single run is
+    launch-bound, a batch of 8 costs little more than one run.
+    ``concurrent`` > 1 runs that many of a rank's points (or batches) at once, each on its own solver context
     (own HIP stream, own copy of the mesh): at stock mesh sizes one point cannot fill an MI355X
     (its kernels are latency-bound), so overlapping points raises the per-GPU throughput.
 
@@ -321,6 +369,15 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
     # folder per point as sweep_test.py:63 names it ("3.80"); more digits only if two points would share a folder
     digits = 2 if len({f"{k:.2f}" for k in k_values}) == len(list(k_values)) else 4
 
+    def rmse_against_experiment(c, res):
+        ps, os_ = res["watchers"]["pside"], res["watchers"]["oside"]
+        span = ps.max() - ps.min()
+        sim_o = (os_ - os_[0]) / span
+        ic = float(c["heating"]["ic_temp"])
+        exp_o = exp["oside"] - exp["oside"][0] + ic
+        exp_o = (exp_o - exp_o[0]) / (exp["temp"].max() - exp["temp"].min())
+        return calculate_rmse(exp["time"], exp_o, res["times"], sim_o)
+
     def one_point(k, sess):
         c = copy.deepcopy(cfg)
         c["mats"]["p_sample"]["k"] = float(k)
@@ -332,18 +389,34 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
                                       False, True, session=sess, read_flux=False)
             row.update(status="success", runtime=time.time() - t0, pcg_iters_mean=float(np.mean(res["iters"])))
             if exp is not None:
-                ps, os_ = res["watchers"]["pside"], res["watchers"]["oside"]
-                span = ps.max() - ps.min()
-                sim_o = (os_ - os_[0]) / span
-                ic = float(c["heating"]["ic_temp"])
-                exp_o = exp["oside"] - exp["oside"][0] + ic
-                exp_o = (exp_o - exp_o[0]) / (exp["temp"].max() - exp["temp"].min())
-                row["rmse"] = calculate_rmse(exp["time"], exp_o, res["times"], sim_o)
+                row["rmse"] = rmse_against_experiment(c, res)
         except Exception as e:
             row.update(error=str(e))
         return row
 
-    mine = [k for _, k in shard(list(k_values), rank, world)]
+    def many_points(ks, sess):
+        """len(ks) in (2, 4, 8): one batched loop; every point is re-run on its own if the batch fails."""
+        cfgs = []
+        for k in ks:
+            c = copy.deepcopy(cfg)
+            c["mats"]["p_sample"]["k"] = float(k)
+            cfgs.append(c)
+        t0 = time.time()
+        try:
+            results = run_simulation_batch_impl(stack.kind, cfgs, [os.path.join(output_dir, f"{k:.{digits}f}") for k in ks],
+                                                [get_watcher_points(c) for c in cfgs], sess, True)
+        except Exception:
+            return [one_point(k, sess) for k in ks]
+        rows_ = []
+        for k, c, res in zip(ks, cfgs, results):
+            row = {"k": float(k), "rmse": float("nan"), "runtime": (time.time() - t0) / len(ks), "status": "success", "error": None,
+                   "rank": rank, "pcg_iters_mean": float(np.mean(res["iters"])), "batch": len(ks)}
+            if exp is not None:
+                row["rmse"] = rmse_against_experiment(c, res)
+            rows_.append(row)
+        return rows_
+
+    mine = batch_groups([k for _, k in shard(list(k_values), rank, world)], batch)
     sessions = [session]
     rows = []
     try:
@@ -372,22 +445,23 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
             for sess in sessions:
                 free.put(sess)
 
-            def task(k):
+            def task(ks):
                 sess = free.get()
                 try:
-                    return one_point(k, sess)
+                    return [one_point(ks[0], sess)] if len(ks) == 1 else many_points(ks, sess)
                 finally:
                     free.put(sess)
 
             with ThreadPoolExecutor(max_workers=len(sessions)) as pool:
-                rows = list(pool.map(task, mine))
+                rows = [r for part in pool.map(task, mine) for r in part]
         else:
-            rows = [one_point(k, session) for k in mine]
+            rows = [r for ks in mine for r in ([one_point(ks[0], session)] if len(ks) == 1 else many_points(ks, session))]
         if on_done is not None:
             on_done()
         if timing is not None:
             timing["points_s"] = time.perf_counter() - t_phase
-            timing["points_here"] = len(mine)
+            timing["points_here"] = sum(len(ks) for ks in mine)
+            timing["batches"] = [len(ks) for ks in mine]
             timing["sessions"] = len(sessions)
     finally:
         for sess in sessions:

@@ -169,17 +169,24 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_bc_all, double rtol, do
  * and of the kappa list, sweep_test.py:47-52).  Vectors are stored interleaved on the device, every index and every
  * shared matrix value is read once for nv products, and each column keeps its own alpha / beta / tolerance /
  * iteration count / done flag; per column the arithmetic and the stopping rule are hf_step's.
- *   per_column_operator = 0  all columns share the context's assembled operator (points that differ in their
- *                            boundary values only: fwhm, heating curve)
- *   per_column_operator = 1  every column has its own A_hat (kappa sweep): assemble a point's operator in the
- *                            context as usual (hf_update_kappa), then hf_batch_load_column(j) copies A_hat, D^-1
- *                            and the lifting values into column j.  The multigrid hierarchy is the frozen one
- *                            (hf_set_precond(1, reuse = 1)) and is shared by all columns.
+ *   HF_BATCH_SHARED      all columns share the context's assembled operator (points that differ in their boundary
+ *                        values only: fwhm, heating curve)
+ *   HF_BATCH_PER_COLUMN  every column has its own A_hat: assemble a point's operator in the context as usual
+ *                        (hf_update_kappa), then hf_batch_load_column(j) copies A_hat, D^-1 and the lifting values
+ *                        into column j
+ *   HF_BATCH_AFFINE      A_hat_j = A_hat + delta_j * A1 with A1 = dt K restricted to the listed materials at unit
+ *                        conductivity (hf_batch_set_affine): a sweep over ONE conductivity (sweep_test.py's kappa_sample
+ *                        list) needs two shared value arrays and a scalar per column instead of nv operators;
+ *                        delta_j = kappa_j - the conductivity the context's operator was assembled with
+ * With per-column or affine operators the multigrid hierarchy is the frozen one (hf_set_precond(1, reuse = 1)), shared
+ * by all columns.
  * hf_batch_begin needs a completed hf_assemble; hf_set_mesh / hf_set_dirichlet / hf_set_precond close the batch.
  * hf_batch_run: g_bc_all = n_steps x n_bc x nv ([step][bc][column]); samples = n_steps x nv x n_s; iters =
  * n_steps x nv.  The start vector of every solve is 2 u^n - u^{n-1}.  HF_ERR_NOCONV if any column fails. */
-int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t per_column_operator);
+enum { HF_BATCH_SHARED = 0, HF_BATCH_PER_COLUMN = 1, HF_BATCH_AFFINE = 2 };
+int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t operator_kind);
 int hf_batch_load_column(hf_ctx* ctx, int32_t j);
+int hf_batch_set_affine(hf_ctx* ctx, int32_t n_tags, const int32_t* tags, const double* delta /* nv */);
 int hf_batch_set_state(hf_ctx* ctx, int32_t j, const double* u);
 int hf_batch_get_state(hf_ctx* ctx, int32_t j, double* u);
 int hf_batch_run(hf_ctx* ctx, int32_t n_steps, const double* g_bc_all, double rtol, double atol, int32_t max_it,

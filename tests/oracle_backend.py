@@ -52,6 +52,7 @@ class OracleBackend:
         self.n_bc = len(self.bc_dofs)
 
     def assemble(self, dt, mode=0):
+        self._dt = dt
         kappa, rho_c = ho.cell_coefficients(self.tags, self.tag_to_k, self.tag_to_rc)
         Me, Ke = ho.element_matrices(self.coords, self.tris, rho_c, kappa)
         self.M = ho.assemble_csr(self.n, self.tris, Me)
@@ -87,6 +88,50 @@ class OracleBackend:
             if ns:
                 samples[k] = self.u[np.asarray(nodes)]
         return samples, np.ones(len(g_all), dtype=np.int32)
+
+    # -- batched loop stand-in: every column solved on its own with its own factorisation --------
+    def batch_begin(self, nv, per_column_operator=False):
+        self.batch_nv, self._bpercol = int(nv), bool(per_column_operator)
+        self._bcols = [dict(u=None, M=self.M, lu=self._lu, lift=self.A_lift) for _ in range(nv)]
+        self.batch_begin_calls = getattr(self, "batch_begin_calls", 0) + 1
+
+    def batch_load_column(self, j):
+        self._bcols[j].update(M=self.M, lu=self._lu, lift=self.A_lift)
+
+    def batch_set_affine(self, tags, delta):
+        ref = dict(self.tag_to_k)
+        for j, d in enumerate(delta):
+            self.tag_to_k = {t: (k + float(d) if t in set(int(x) for x in tags) else k) for t, k in ref.items()}
+            self.assemble(self._dt)
+            self.batch_load_column(j)
+        self.tag_to_k = ref
+        self.assemble(self._dt)
+        self.batch_affine_calls = getattr(self, "batch_affine_calls", 0) + 1
+
+    def batch_set_state(self, j, u):
+        self._bcols[j]["u"] = np.array(u, dtype=np.float64).copy()
+
+    def batch_get_state(self, j):
+        return self._bcols[j]["u"].copy()
+
+    def batch_run(self, g_all, rtol=1e-10, atol=0.0, max_it=20000, nodes=None):
+        nsteps, _, nv = g_all.shape
+        ns = 0 if nodes is None else len(nodes)
+        samples = np.empty((nsteps, nv, ns))
+        for s in range(nsteps):
+            for j, col in enumerate(self._bcols):
+                b = col["M"] @ col["u"]
+                if self.n_bc:
+                    g = np.ascontiguousarray(g_all[s, :, j])
+                    b -= col["lift"] @ g
+                    b[self.bc_dofs] = g
+                col["u"] = col["lu"].solve(b)
+                if ns:
+                    samples[s, j] = col["u"][np.asarray(nodes)]
+        return samples, np.ones((nsteps, nv), dtype=np.int32)
+
+    def batch_end(self):
+        self.batch_nv = 0
 
     def flux_setup(self):
         self._proj = ho.GradientProjector(self.coords, self.tris)

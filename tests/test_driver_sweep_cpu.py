@@ -321,3 +321,51 @@ def test_session_is_not_reused_for_a_different_dirichlet_set_with_the_same_dof_s
     assert sess._key != key1 and sess._key[:2] == key1[:2]
     assert int(dofs1.sum()) == int(sess.problem.bc_dofs.sum()) and not np.array_equal(dofs1, sess.problem.bc_dofs)
     assert be.set_mesh_calls == 2               # a new HeatProblem was built for the new Dirichlet set
+
+
+def test_batched_sweeps_give_the_same_rows_and_files_as_point_by_point(tmp_path):
+    """batch = 8 in both sweep drivers: points are grouped 8 / 4 / 2 / 1, advance together (here through the oracle
+    stand-in of the batched loop) and leave the same artefacts and numbers as the unbatched sweep."""
+    assert [len(g) for g in ps.batch_groups(list(range(15)), 8)] == [8, 4, 2, 1]
+    assert [len(g) for g in ps.batch_groups(list(range(7)), 4)] == [4, 2, 1]
+    assert [len(g) for g in ps.batch_groups(list(range(3)), 1)] == [1, 1, 1]
+    from heatflow_amd.driver import prepare_mesh
+    from heatflow_amd.geometry import build_stack
+
+    cfg = _cfg("geballe_with_diamond", 16.0, 10)
+    cfg["heating"]["file"] = os.path.join(ROOT, cfg["heating"]["file"])
+    mesh = str(tmp_path / "mesh")
+    prepare_mesh(cfg, mesh, True, build_stack(cfg))
+    ks = [3.3, 3.45, 3.6, 3.75, 3.9, 4.05, 4.2]
+    made = []
+
+    def factory(*a, **kw):
+        made.append(_session_factory(*a, **kw))
+        return made[-1]
+
+    timing = {}
+    rows_b = ps.run_kappa_sweep(cfg, mesh, ks, str(tmp_path / "outb"), session_factory=factory, batch=4, timing=timing)
+    rows_1 = ps.run_kappa_sweep(cfg, mesh, ks, str(tmp_path / "out1"), session_factory=_session_factory)
+    assert timing["batches"] == [4, 2, 1] and made[0].backend.batch_begin_calls == 2
+    assert [r["status"] for r in rows_b] == ["success"] * 7 and [r["k"] for r in rows_b] == ks
+    assert [r.get("batch") for r in rows_b] == [4, 4, 4, 4, 2, 2, None]
+    for k in ks:
+        a = np.genfromtxt(os.path.join(str(tmp_path / "outb"), f"{k:.2f}", "watcher_points.csv"), delimiter=",", names=True)
+        b = np.genfromtxt(os.path.join(str(tmp_path / "out1"), f"{k:.2f}", "watcher_points.csv"), delimiter=",", names=True)
+        assert np.abs(a["oside"] - b["oside"]).max() < 1e-9 and np.abs(a["pside"] - b["pside"]).max() < 1e-9
+        assert os.path.isfile(os.path.join(str(tmp_path / "outb"), f"{k:.2f}", "used_config.yaml"))
+    # fwhm x k grid of parameter_sweep on the with-diamond stack: 3 x 2 points, batched 4 + 2
+    cfg_path = str(tmp_path / "base.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    args = (cfg_path, None, (8e-6, 2e-5), (3.0, 5.0), (1.84e-6, 1.84e-6), (3, 2, 1))
+    ok_b, failed_b = ps.run_parameter_sweep(args[0], str(tmp_path / "gb"), *args[2:], base_mesh_folder=str(tmp_path / "gm"),
+                                            session_factory=_session_factory, batch=8)
+    ok_1, failed_1 = ps.run_parameter_sweep(args[0], str(tmp_path / "g1"), *args[2:], base_mesh_folder=str(tmp_path / "gm"),
+                                            session_factory=_session_factory)
+    assert len(ok_b) == 6 and not failed_b and not failed_1 and [r.get("batch") for r in ok_b] == [4, 4, 4, 4, 2, 2]
+    for a, b in zip(ok_b, ok_1):
+        assert a["run_name"] == b["run_name"] and a["run_id"] == b["run_id"]
+        wa = np.genfromtxt(os.path.join(a["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
+        wb = np.genfromtxt(os.path.join(b["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
+        assert np.abs(wa["oside"] - wb["oside"]).max() < 1e-9

@@ -899,9 +899,10 @@ def test_pattern_blob_export_and_prebuilt_install(hip, case_with_diamond_small):
                 assert np.array_equal(x, y)
         assert np.array_equal(b.export_pattern(), blob)   # and exports the same blob again
     # a blob in device memory (what an RCCL broadcast leaves behind): plain hipMalloc through the HIP runtime the
-    # library itself uses (torch's bundled runtime cannot be initialised after it in one process)
+    # library itself is linked against (dlsym on its handle searches its dependencies; another copy of the runtime,
+    # e.g. torch's bundled one, may be loaded in this process too)
     import ctypes as C
-    rt = C.CDLL("libamdhip64.so")
+    rt = hip.load_library()
     rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     rt.hipFree.argtypes = [C.c_void_p]
@@ -952,9 +953,10 @@ def test_pattern_blob_export_and_prebuilt_install(hip, case_with_diamond_small):
         assert d.n == len(mesh.coords)
 
 
+@pytest.mark.parametrize("kind", ["per_column", "affine"])
 @pytest.mark.parametrize("precond", [0, 1])
 @pytest.mark.parametrize("nv", [2, 4, 8])
-def test_batched_time_loop_with_per_column_operators_matches_single_runs_and_oracle(hip, nv, precond, case_with_diamond_small):
+def test_batched_time_loop_with_per_column_operators_matches_single_runs_and_oracle(hip, nv, precond, kind, case_with_diamond_small):
     """hf_batch_*: nv kappa_sample values advance together as interleaved columns (per-column fine operator,
     shared frozen hierarchy).  Every column must match the oracle's run for its kappa at every step (<= 1e-4 K)
     and the single-column run of the same context to solver tolerance."""
@@ -979,10 +981,17 @@ def test_batched_time_loop_with_per_column_operators_matches_single_runs_and_ora
             prob.set_state(300.0)
             _, it1 = be.run(g_one, prob.rtol, 0.0, prob.max_it, None)
             singles.append((prob.state(), it1))
-        be.batch_begin(nv, per_column_operator=True)
-        for j, kap in enumerate(ks):
-            be.update_kappa([tag_s], [kap])
-            be.batch_load_column(j)
+        if kind == "affine":                             # A_j = A(kappa_ref) + (kappa_j - kappa_ref) dt K_sample
+            ref_k = ks[nv // 2]
+            be.update_kappa([tag_s], [ref_k])
+            be.batch_begin(nv, per_column_operator=hip.BATCH_AFFINE)
+            be.batch_set_affine([tag_s], [kap - ref_k for kap in ks])
+        else:
+            be.batch_begin(nv, per_column_operator=hip.BATCH_PER_COLUMN)
+            for j, kap in enumerate(ks):
+                be.update_kappa([tag_s], [kap])
+                be.batch_load_column(j)
+        for j in range(nv):
             be.batch_set_state(j, np.full(prob.n, 300.0))
         g_all = np.repeat(g_one[:, :, None], nv, axis=2)
         nodes = np.array([0, prob.n // 2, prob.n - 1], dtype=np.int32)
