@@ -193,9 +193,9 @@ __global__ __launch_bounds__(TPB) void kb_spmv(int n, const int32_t* __restrict_
 
 // Generic CSR operator (shared values) times NV interleaved columns: LANES lanes share a row, each keeps NV
 // accumulators, so every index and value is read once.  VMODE 0: y = A x, 1: y += A x.
-template <int NV, int LANES, int VMODE>
+template <int NV, int LANES, int VMODE, typename VT>
 __global__ __launch_bounds__(TPB) void kb_csr(int nrow, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-                                              const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y) {
+                                              const VT* __restrict__ val, const double* __restrict__ x, double* __restrict__ y) {
   const int lane = threadIdx.x % LANES;
   const int rows_per_pass = (gridDim.x * TPB) / LANES;
   for (int row = (blockIdx.x * TPB + threadIdx.x) / LANES; row < nrow; row += rows_per_pass) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(TPB) void kb_csr(int nrow, const int32_t* __restric
     for (int k = ptr[row] + lane; k < k1; k += 2 * LANES) {
       const bool in2 = k + LANES < k1;
       const int c0 = idx[k], c1 = in2 ? idx[k + LANES] : 0;
-      const double v0 = val[k], v1 = in2 ? val[k + LANES] : 0.0;
+      const double v0 = static_cast<double>(val[k]), v1 = in2 ? static_cast<double>(val[k + LANES]) : 0.0;
       const double* x0 = x + static_cast<size_t>(c0) * NV;
       const double* x1 = x + static_cast<size_t>(c1) * NV;
       double a0[NV], a1[NV];
@@ -229,19 +229,19 @@ __global__ __launch_bounds__(TPB) void kb_csr(int nrow, const int32_t* __restric
 
 // x = Ainv b, dense inverse of the coarsest operator (row-major, leading dimension ld), NV interleaved columns:
 // one wavefront per row, every matrix entry read once.
-template <int NV>
-__global__ __launch_bounds__(TPB) void kb_dense(int n, int ld, const double* __restrict__ Ainv, const double* __restrict__ b,
+template <int NV, typename VT>
+__global__ __launch_bounds__(TPB) void kb_dense(int n, int ld, const VT* __restrict__ Ainv, const double* __restrict__ b,
                                                 double* __restrict__ x) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * TPB) >> 6;
   for (int row = wave; row < n; row += nwaves) {
-    const double* arow = Ainv + static_cast<size_t>(row) * ld;
+    const VT* arow = Ainv + static_cast<size_t>(row) * ld;
     double acc[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) acc[j] = 0.0;
     for (int c = lane; c < n; c += 64) {
-      const double a = arow[c];
+      const double a = static_cast<double>(arow[c]);
       const double* bc = b + static_cast<size_t>(c) * NV;
 #pragma unroll
       for (int j = 0; j < NV; ++j) acc[j] += a * bc[j];
@@ -412,13 +412,13 @@ void free_batch(hf_ctx* ctx) {
   B.nv = 0;
 }
 
-template <int NV, int VMODE>
-void blaunch_csr(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
+template <int NV, int VMODE, typename VT>
+void blaunch_csr_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y) {
   const double avg = m.nrow ? static_cast<double>(m.nnz) / m.nrow : 1.0;
   const int lanes = avg <= 2.5 ? 2 : avg <= 5.0 ? 4 : avg <= 10.0 ? 8 : avg <= 20.0 ? 16 : avg <= 40.0 ? 32 : 64;
   const long long threads = static_cast<long long>(m.nrow) * lanes;
   const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 4096)));
-#define HF_BCSR(L) hipLaunchKernelGGL((kb_csr<NV, L, VMODE>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, m.val, x, y)
+#define HF_BCSR(L) hipLaunchKernelGGL((kb_csr<NV, L, VMODE, VT>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, val, x, y)
   switch (lanes) {
     case 2: HF_BCSR(2); break;
     case 4: HF_BCSR(4); break;
@@ -428,6 +428,12 @@ void blaunch_csr(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
     default: HF_BCSR(64); break;
   }
 #undef HF_BCSR
+}
+
+template <int NV, int VMODE>
+void blaunch_csr(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
+  if (m.valf != nullptr) blaunch_csr_t<NV, VMODE, float>(c, m, m.valf, x, y);
+  else blaunch_csr_t<NV, VMODE, double>(c, m, m.val, x, y);
 }
 
 template <int NV, int OPK>
@@ -490,8 +496,12 @@ struct BatchOps {
       const DevLevel& Lc = c->amg[nl - 1];
       if (c->coarse_n > 0) {
         const int g = std::max(1, std::min((Lc.n + 3) / 4, 1024));
-        hipLaunchKernelGGL((kb_dense<NV>), dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv, B.lev[nl - 1].b,
-                           B.lev[nl - 1].res);
+        if (c->d_coarse_inv_f != nullptr)
+          hipLaunchKernelGGL((kb_dense<NV, float>), dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv_f,
+                             B.lev[nl - 1].b, B.lev[nl - 1].res);
+        else
+          hipLaunchKernelGGL((kb_dense<NV, double>), dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv,
+                             B.lev[nl - 1].b, B.lev[nl - 1].res);
       } else {
         const int g = std::max(1, std::min((Lc.n * NV + TPB - 1) / TPB, 1024));
         hipLaunchKernelGGL((kb_scale<NV>), dim3(g), dim3(TPB), 0, c->stream, Lc.n, Lc.omega, Lc.dinv, B.lev[nl - 1].b, B.lev[nl - 1].res);

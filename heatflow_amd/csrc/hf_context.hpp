@@ -138,8 +138,12 @@ struct hf_ctx {
   bool amg_ready = false;
   struct DevCsr {
     int nrow = 0, ncol = 0, lanes = 8; int64_t nnz = 0; int32_t *ptr = nullptr, *idx = nullptr; double* val = nullptr;
+    float* valf = nullptr;                     // single-precision values (transfer operators of the preconditioner); val is then null
     int max_row = 0;
     int rpc = 0, nchunks = 0, chunk_nnz = 0;   // LDS-staged (stream) kernel geometry; rpc = 0 -> use the sub-wave kernel
+    int32_t *dptr = nullptr, *dict = nullptr;  // stream kernel with compressed columns: per-chunk column lists ...
+    uint16_t* cid = nullptr;                   // ... and a 16-bit position per nonzero
+    int max_dict = 0;
   };
   // Levels 1..nl-2 run the cycle through the fused legs Rt / GP (amg_host.hpp): `cat` = [b_l ; result of level l+1]
   // is GP's operand, `b` aliases its head; a level's result goes to `res` (the tail of the finer level's cat,
@@ -152,7 +156,9 @@ struct hf_ctx {
   };
   std::vector<DevLevel> amg;
   double* d_coarse_inv = nullptr;
-  int coarse_n = 0, coarse_ld = 0;   // dense inverse, row-major with an even leading dimension (16-byte row loads)
+  float* d_coarse_inv_f = nullptr;   // the same in single precision (amg_f32)
+  int coarse_n = 0, coarse_ld = 0;   // dense inverse, row-major, leading dimension a multiple of 4 (16-byte row loads)
+  bool amg_f32 = true;               // operators of the preconditioner below the fine level stored in float (HEATFLOW_AMG_F32=0: double)
   double amg_opc = 0.0, amg_setup_s = 0.0;
   long long amg_fallbacks = 0;   // steps finished by Jacobi-PCG after a multigrid-PCG breakdown
   double *d_z = nullptr, *d_z2 = nullptr;

@@ -574,10 +574,10 @@ __global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* 
 // gather) and the products look it up there: 10 instead of 12 bytes per nonzero, 5x fewer global gathers.
 struct ColComp { const int32_t* dptr; const int32_t* dict; const uint16_t* id; int xd_off; };
 
-template <int MODE, bool C16 = false>
+template <int MODE, bool C16 = false, typename VT = double>
 __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows per chunk, <= TS */,
                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                              const double* __restrict__ vals, const double* __restrict__ x,
+                                              const VT* __restrict__ vals, const double* __restrict__ x,
                                               double* __restrict__ y, Scal* __restrict__ scal,
                                               double* __restrict__ part0, const double* __restrict__ bvec,
                                               const double* __restrict__ dinv, double* __restrict__ pvec,
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
 #pragma unroll
       for (int u = 0; u < HF_UNROLL; ++u) {
         const bool in = k + u * TS < k1;
-        v[u] = in ? vals[k + u * TS] : 0.0;
+        v[u] = in ? static_cast<double>(vals[k + u * TS]) : 0.0;
         id[u] = in ? static_cast<int>(comp.id[k + u * TS]) : 0;
       }
       for (int i = threadIdx.x; i < nd; i += TS) xd[i] = x[comp.dict[d0 + i]];
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
 #pragma unroll
         for (int u = 0; u < HF_UNROLL; ++u) {
           const bool in = kn + u * TS < k1;
-          vn[u] = in ? vals[kn + u * TS] : 0.0;
+          vn[u] = in ? static_cast<double>(vals[kn + u * TS]) : 0.0;
           idn[u] = in ? static_cast<int>(comp.id[kn + u * TS]) : 0;
         }
 #pragma unroll
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
         for (int u = 0; u < HF_UNROLL; ++u) {
           const bool in = k + u * TS < k1;
           c[u] = in ? colidx[k + u * TS] : 0;
-          v[u] = in ? vals[k + u * TS] : 0.0;
+          v[u] = in ? static_cast<double>(vals[k + u * TS]) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < HF_UNROLL; ++u) xv[u] = (k + u * TS < k1) ? x[c[u]] : 0.0;
@@ -807,9 +807,9 @@ __global__ __launch_bounds__(TPB) void k_pcg_update(int n, int nchunks, int P, i
 // flight per lane (the fused legs have rows of hundreds of entries), fixed-order shuffle reduction.
 //   VMODE 0: y = A x      1: y += A x
 // ------------------------------------------------------------------------------------------
-template <int LANES, int VMODE>
+template <int LANES, int VMODE, typename VT = double>
 __global__ __launch_bounds__(TPB) void k_spmv_vec(int nrow, const int32_t* __restrict__ ptr,
-                                                  const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                  const int32_t* __restrict__ idx, const VT* __restrict__ val,
                                                   const double* __restrict__ x, double* __restrict__ y,
                                                   const Scal* __restrict__ scal) {
   if (scal->done) return;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(TPB) void k_spmv_vec(int nrow, const int32_t* __res
       for (int u = 0; u < 4; ++u) {
         const bool in = k + u * LANES < k1;
         c[u] = in ? idx[k + u * LANES] : 0;
-        v[u] = in ? val[k + u * LANES] : 0.0;
+        v[u] = in ? static_cast<double>(val[k + u * LANES]) : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) xv[u] = (k + u * LANES < k1) ? x[c[u]] : 0.0;
@@ -841,9 +841,9 @@ __global__ __launch_bounds__(TPB) void k_spmv_vec(int nrow, const int32_t* __res
 
 // Same operation for operators with very long rows (the fused down leg onto a small level): a whole
 // workgroup per row, four predicated loads + gathers in flight per lane, fixed-order block reduction.
-template <int VMODE>
+template <int VMODE, typename VT = double>
 __global__ __launch_bounds__(TPB) void k_spmv_row(int nrow, const int32_t* __restrict__ ptr,
-                                                  const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                  const int32_t* __restrict__ idx, const VT* __restrict__ val,
                                                   const double* __restrict__ x, double* __restrict__ y,
                                                   const Scal* __restrict__ scal) {
   __shared__ double s4[TPB / 64];
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(TPB) void k_spmv_row(int nrow, const int32_t* __res
       for (int u = 0; u < 4; ++u) {
         const bool in = k + u * TPB < k1;
         c[u] = in ? idx[k + u * TPB] : 0;
-        v[u] = in ? val[k + u * TPB] : 0.0;
+        v[u] = in ? static_cast<double>(val[k + u * TPB]) : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) xv[u] = (k + u * TPB < k1) ? x[c[u]] : 0.0;
@@ -938,6 +938,43 @@ __global__ __launch_bounds__(TPB) void k_dense_mv(int n, int ld, const double* _
     if (lane == 0 && (wave & 1) == 0 && row < n) x[row] = half_sum[wave] + half_sum[wave + 1];
     __syncthreads();
   }
+}
+
+// The same with the inverse stored in float (the preconditioner's operators are kept in single precision, the
+// vectors and every accumulation stay double): 16-byte loads of four entries.
+__global__ __launch_bounds__(TPB) void k_dense_mv_f32(int n, int ld /* multiple of 4 */, const float* __restrict__ Ainv,
+                                                      const double* __restrict__ b, double* __restrict__ x,
+                                                      const Scal* __restrict__ scal) {
+  __shared__ double half_sum[4];
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int npair = (n + 1) >> 1;
+  for (int pr = blockIdx.x; pr < npair; pr += gridDim.x) {
+    const int row = 2 * pr + (wave >> 1);
+    double s = 0.0;
+    if (row < n) {
+      const float4* arow = reinterpret_cast<const float4*>(Ainv + static_cast<size_t>(row) * ld);
+      const double2* bv = reinterpret_cast<const double2*>(b);
+      const int nv = ld >> 2;
+      for (int j = (wave & 1) * 64 + lane; j < nv; j += 128) {
+        const float4 a = arow[j];
+        const double2 v0 = bv[2 * j], v1 = bv[2 * j + 1];
+        s += static_cast<double>(a.x) * v0.x + static_cast<double>(a.y) * v0.y + static_cast<double>(a.z) * v1.x + static_cast<double>(a.w) * v1.y;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) half_sum[wave] = s;
+    __syncthreads();
+    if (lane == 0 && (wave & 1) == 0 && row < n) x[row] = half_sum[wave] + half_sum[wave + 1];
+    __syncthreads();
+  }
+}
+
+__global__ void k_to_float(size_t n, const double* __restrict__ src, float* __restrict__ dst) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x)
+    dst[i] = static_cast<float>(src[i]);
 }
 
 // Dense inverse of the coarsest operator on the GPU: Gauss-Jordan without pivoting (the operator

@@ -46,14 +46,16 @@ struct Pattern {
 };
 
 // false when a chunk touches more than 65535 columns (16-bit positions)
-bool build_coldict(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int32_t n, int rows, ColDict& D) {
+bool build_coldict(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int32_t n, int rows, ColDict& D,
+                   int32_t ncol = -1) {
+  if (ncol < 0) ncol = n;
   const int nchunk = (n + rows - 1) / rows;
   D.ptr.assign(static_cast<size_t>(nchunk) + 1, 0);
   D.dict.clear();
   D.dict.reserve(static_cast<size_t>(n) + n / 2);
   D.id.resize(colidx.size());
   D.max_dict = 0;
-  std::vector<int32_t> seen(n, -1), lid(n, 0), list;
+  std::vector<int32_t> seen(ncol, -1), lid(ncol, 0), list;
   for (int c = 0; c < nchunk; ++c) {
     const int64_t k0 = rowptr[static_cast<size_t>(c) * rows], k1 = rowptr[std::min<int64_t>(n, (c + 1LL) * rows)];
     list.clear();

@@ -10,7 +10,7 @@ namespace {
 using DevCsr = hf_ctx::DevCsr;
 using DevLevel = hf_ctx::DevLevel;
 
-void free_dev_csr(DevCsr& m) { dev_free(&m.ptr); dev_free(&m.idx); dev_free(&m.val); m = DevCsr(); }
+void free_dev_csr(DevCsr& m) { dev_free(&m.ptr); dev_free(&m.idx); dev_free(&m.val); dev_free(&m.valf); dev_free(&m.dptr); dev_free(&m.dict); dev_free(&m.cid); m = DevCsr(); }
 
 void free_amg(hf_ctx* ctx) {
   for (size_t l = 0; l < ctx->amg.size(); ++l) {
@@ -21,6 +21,7 @@ void free_amg(hf_ctx* ctx) {
   }
   ctx->amg.clear();
   dev_free(&ctx->d_coarse_inv);
+  dev_free(&ctx->d_coarse_inv_f);
   ctx->coarse_n = 0;
   ctx->amg_ready = false;
 }
@@ -30,7 +31,10 @@ int lanes_for(const amg::Csr& m) {
   return avg <= 4.5 ? 4 : avg <= 9.0 ? 8 : avg <= 18.0 ? 16 : avg <= 36.0 ? 32 : avg <= 128.0 ? 64 : 256;
 }
 
-int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d) {
+// f32: values stored in single precision (operators that only act inside the preconditioner).  Operators big enough
+// for the LDS-staged kernel also get its compressed column stream (a sorted column list per chunk + a 16-bit position
+// per nonzero): 6 instead of 12 bytes per nonzero together.
+int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d, bool f32 = false) {
   d.nrow = h.nrow; d.ncol = h.ncol; d.nnz = h.nnz(); d.lanes = lanes_for(h);
   for (int i = 0; i < h.nrow; ++i) d.max_row = std::max(d.max_row, h.ptr[i + 1] - h.ptr[i]);
   d.rpc = 0;
@@ -45,11 +49,27 @@ int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d) {
   }
   HF_TRY(dev_alloc(ctx, &d.ptr, h.ptr.size()));
   HF_TRY(dev_alloc(ctx, &d.idx, h.idx.size()));
-  HF_TRY(dev_alloc(ctx, &d.val, h.val.size()));
   HF_HIP(copy_sync(ctx, d.ptr, h.ptr.data(), sizeof(int32_t) * h.ptr.size(), hipMemcpyHostToDevice));
-  if (!h.idx.empty()) {
-    HF_HIP(copy_sync(ctx, d.idx, h.idx.data(), sizeof(int32_t) * h.idx.size(), hipMemcpyHostToDevice));
-    HF_HIP(copy_sync(ctx, d.val, h.val.data(), sizeof(double) * h.val.size(), hipMemcpyHostToDevice));
+  if (!h.idx.empty()) HF_HIP(copy_sync(ctx, d.idx, h.idx.data(), sizeof(int32_t) * h.idx.size(), hipMemcpyHostToDevice));
+  if (f32) {
+    std::vector<float> vf(h.val.begin(), h.val.end());
+    HF_TRY(dev_alloc(ctx, &d.valf, vf.size()));
+    if (!vf.empty()) HF_HIP(copy_sync(ctx, d.valf, vf.data(), sizeof(float) * vf.size(), hipMemcpyHostToDevice));
+  } else {
+    HF_TRY(dev_alloc(ctx, &d.val, h.val.size()));
+    if (!h.val.empty()) HF_HIP(copy_sync(ctx, d.val, h.val.data(), sizeof(double) * h.val.size(), hipMemcpyHostToDevice));
+  }
+  if (f32 && d.rpc > 0) {   // compressed column stream for the LDS-staged kernel
+    ColDict cd;
+    if (build_coldict(h.ptr, h.idx, h.nrow, d.rpc, cd, h.ncol) && static_cast<size_t>(d.chunk_nnz + cd.max_dict) * 8 <= 64 * 1024) {
+      d.max_dict = cd.max_dict;
+      HF_TRY(dev_alloc(ctx, &d.dptr, cd.ptr.size()));
+      HF_TRY(dev_alloc(ctx, &d.dict, cd.dict.size()));
+      HF_TRY(dev_alloc(ctx, &d.cid, cd.id.size()));
+      HF_HIP(copy_sync(ctx, d.dptr, cd.ptr.data(), sizeof(int32_t) * cd.ptr.size(), hipMemcpyHostToDevice));
+      HF_HIP(copy_sync(ctx, d.dict, cd.dict.data(), sizeof(int32_t) * cd.dict.size(), hipMemcpyHostToDevice));
+      HF_HIP(copy_sync(ctx, d.cid, cd.id.data(), sizeof(uint16_t) * cd.id.size(), hipMemcpyHostToDevice));
+    }
   }
   return HF_OK;
 }
@@ -64,6 +84,8 @@ int build_amg(hf_ctx* ctx) {
   A0.idx.assign(ctx->h_colidx.begin(), ctx->h_colidx.end());
   A0.val.resize(ctx->nnz);
   HF_HIP(copy_sync(ctx, A0.val.data(), ctx->d_A, sizeof(double) * ctx->nnz, hipMemcpyDeviceToHost));
+  if (const char* e = std::getenv("HEATFLOW_AMG_F32")) ctx->amg_f32 = (e[0] != '0');
+  const bool f32 = ctx->amg_f32;
   amg::Hierarchy H;
   amg::Params prm;
   if (const char* e = std::getenv("HEATFLOW_AMG_THETA")) prm.theta = std::atof(e);          // tuning knobs
@@ -89,12 +111,12 @@ int build_amg(hf_ctx* ctx) {
         HF_TRY(dev_alloc(ctx, &L.cat, len));
         HF_HIP(hipMemsetAsync(L.cat, 0, sizeof(double) * len, ctx->stream));
         L.b = L.cat;
-        HF_TRY(upload_csr(ctx, hl.Rt, L.Rt));
-        HF_TRY(upload_csr(ctx, hl.GP, L.GP));
+        HF_TRY(upload_csr(ctx, hl.Rt, L.Rt, f32));
+        HF_TRY(upload_csr(ctx, hl.GP, L.GP, f32));
       } else {                                // coarsest: the dense solve reads b in pairs -> zero pad
-        HF_TRY(dev_alloc(ctx, &L.b, L.n + 2));
+        HF_TRY(dev_alloc(ctx, &L.b, L.n + 4));
         L.own_b = true;
-        HF_HIP(hipMemsetAsync(L.b, 0, sizeof(double) * (L.n + 2), ctx->stream));
+        HF_HIP(hipMemsetAsync(L.b, 0, sizeof(double) * (L.n + 4), ctx->stream));
       }
       if (l == 1) {
         HF_TRY(dev_alloc(ctx, &L.x, L.n + 2));
@@ -103,12 +125,13 @@ int build_amg(hf_ctx* ctx) {
         L.res = ctx->amg[l - 1].cat + ctx->amg[l - 1].n;
       }
     }
-    if (l + 1 < nl) { HF_TRY(upload_csr(ctx, hl.P, L.P)); HF_TRY(upload_csr(ctx, hl.R, L.R)); }
+    if (l + 1 < nl) { HF_TRY(upload_csr(ctx, hl.P, L.P, f32)); HF_TRY(upload_csr(ctx, hl.R, L.R, f32)); }
   }
   if (std::getenv("HEATFLOW_DEBUG")) {
     auto show = [](const char* nm, size_t l, const DevCsr& m) {
-      if (m.nrow) std::fprintf(stderr, "[amg] level %zu %-2s %8d x %8d nnz %9lld (%.1f/row, max %d) %s rpc %d lanes %d\n", l, nm, m.nrow, m.ncol,
-                               static_cast<long long>(m.nnz), static_cast<double>(m.nnz) / m.nrow, m.max_row, m.rpc ? "stream" : "vec", m.rpc, m.lanes);
+      if (m.nrow) std::fprintf(stderr, "[amg] level %zu %-2s %8d x %8d nnz %9lld (%.1f/row, max %d) %s rpc %d lanes %d %s%s\n", l, nm, m.nrow, m.ncol,
+                               static_cast<long long>(m.nnz), static_cast<double>(m.nnz) / m.nrow, m.max_row, m.rpc ? "stream" : "vec", m.rpc, m.lanes,
+                               m.valf ? "f32" : "f64", m.cid ? " c16" : "");
     };
     for (size_t l = 0; l < nl; ++l) {
       show("A", l, ctx->amg[l].A); show("P", l, ctx->amg[l].P); show("R", l, ctx->amg[l].R);
@@ -119,7 +142,7 @@ int build_amg(hf_ctx* ctx) {
   ctx->coarse_n = 0;
   if (nl > 1 && H.coarse_n > 0 && H.coarse_n <= 4096) {
     const int nc = H.coarse_n;
-    const int ld = (nc + 1) & ~1;
+    const int ld = (nc + 3) & ~3;
     const amg::Csr& Ac = H.levels.back().A;
     std::vector<double> dense(static_cast<size_t>(nc) * nc, 0.0), eye(static_cast<size_t>(nc) * nc, 0.0);
     for (int i = 0; i < nc; ++i) {
@@ -146,6 +169,11 @@ int build_amg(hf_ctx* ctx) {
     HF_HIP(hipMemsetAsync(ctx->d_coarse_inv, 0, sizeof(double) * nc * ld, ctx->stream));
     HF_HIP(hipMemcpy2DAsync(ctx->d_coarse_inv, sizeof(double) * ld, d_inv, sizeof(double) * nc, sizeof(double) * nc, nc,
                             hipMemcpyDeviceToDevice, ctx->stream));
+    if (f32) {
+      HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv_f, static_cast<size_t>(nc) * ld));
+      hipLaunchKernelGGL(k_to_float, dim3(1024), dim3(256), 0, ctx->stream, static_cast<size_t>(nc) * ld, ctx->d_coarse_inv, ctx->d_coarse_inv_f);
+      HF_HIP(hipGetLastError());
+    }
     HF_HIP(hipStreamSynchronize(ctx->stream));
     ctx->coarse_ld = ld;
     ctx->coarse_n = nc;
@@ -158,27 +186,33 @@ int build_amg(hf_ctx* ctx) {
 
 // VMODE 0: y = A x, 1: y += A x; LDS-staged kernel when the matrix is big enough to fill the chip,
 // sub-wave kernel otherwise.
-template <int VMODE>
-void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
+template <int VMODE, typename VT>
+void launch_vec_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y) {
   if (m.rpc > 0) {
     constexpr int SM = VMODE == 0 ? 0 : 6;
     int grid = std::min(m.nchunks, MAXP);
     if (grid >= 64) grid &= ~7;
-    hipLaunchKernelGGL(k_spmv<SM>, dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream, m.nrow,
-                       m.nchunks, m.rpc, m.ptr, m.idx, m.val, x, y, c->d_scal, static_cast<double*>(nullptr),
-                       static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), static_cast<double*>(nullptr),
-                       static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0.0, 0, 0, ColComp{nullptr, nullptr, nullptr, 0});
+#define HF_STREAM_ARGS m.nrow, m.nchunks, m.rpc, m.ptr, m.idx, val, x, y, c->d_scal, static_cast<double*>(nullptr),                       \
+                       static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), static_cast<double*>(nullptr),   \
+                       static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0.0, 0, 0
+    if (m.cid != nullptr)
+      hipLaunchKernelGGL((k_spmv<SM, true, VT>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz + m.max_dict) * 8, c->stream,
+                         HF_STREAM_ARGS, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz});
+    else
+      hipLaunchKernelGGL((k_spmv<SM, false, VT>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream,
+                         HF_STREAM_ARGS, ColComp{nullptr, nullptr, nullptr, 0});
+#undef HF_STREAM_ARGS
     return;
   }
   if (m.lanes > 64) {  // very long rows: a workgroup per row
-    hipLaunchKernelGGL(k_spmv_row<VMODE>, dim3(std::max(1, std::min(m.nrow, 4096))), dim3(TPB), 0, c->stream, m.nrow, m.ptr,
-                       m.idx, m.val, x, y, c->d_scal);
+    hipLaunchKernelGGL((k_spmv_row<VMODE, VT>), dim3(std::max(1, std::min(m.nrow, 4096))), dim3(TPB), 0, c->stream, m.nrow, m.ptr,
+                       m.idx, val, x, y, c->d_scal);
     return;
   }
   const int lanes = m.lanes;
   const long long threads = static_cast<long long>(m.nrow) * lanes;
   const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 2048)));
-#define HF_VEC(L) hipLaunchKernelGGL((k_spmv_vec<L, VMODE>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, m.val, x, y, c->d_scal)
+#define HF_VEC(L) hipLaunchKernelGGL((k_spmv_vec<L, VMODE, VT>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, val, x, y, c->d_scal)
   switch (lanes) {
     case 4: HF_VEC(4); break;
     case 8: HF_VEC(8); break;
@@ -187,6 +221,14 @@ void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
     default: HF_VEC(64); break;
   }
 #undef HF_VEC
+}
+
+// VMODE 0: y = A x, 1: y += A x; LDS-staged kernel when the matrix is big enough to fill the chip,
+// sub-wave kernel otherwise; double or single precision values.
+template <int VMODE>
+void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
+  if (m.valf != nullptr) launch_vec_t<VMODE, float>(c, m, m.valf, x, y);
+  else launch_vec_t<VMODE, double>(c, m, m.val, x, y);
 }
 
 // z = B r: one V(1,1) cycle.  Fixed buffer roles (no pointer swaps): on entry d_z holds w0 D^-1 r (written by the update / start kernel); on exit
@@ -207,8 +249,10 @@ void vcycle(hf_ctx* c, int out_slot) {
     DevLevel& Lc = c->amg[nl - 1];
     if (c->coarse_n > 0) {
       const int g = std::max(1, std::min((Lc.n + 1) / 2, 2048));
-      hipLaunchKernelGGL(k_dense_mv, dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv, Lc.b, Lc.res,
-                         c->d_scal);
+      if (c->d_coarse_inv_f != nullptr)
+        hipLaunchKernelGGL(k_dense_mv_f32, dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv_f, Lc.b, Lc.res, c->d_scal);
+      else
+        hipLaunchKernelGGL(k_dense_mv, dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv, Lc.b, Lc.res, c->d_scal);
     } else {
       const int g = std::max(1, std::min((Lc.n + TPB - 1) / TPB, 1024));
       hipLaunchKernelGGL(k_scale, dim3(g), dim3(TPB), 0, c->stream, Lc.n, Lc.omega, Lc.dinv, Lc.b, Lc.res, c->d_scal);

@@ -16,7 +16,8 @@ def short(name):
         return name[:30]
     targs = m.group(2) or ""
     if m.group(1) == "k_spmv":
-        targs = re.sub(r",\s*(true|false)", "", targs)             # k_spmv<9, true> (compressed columns) -> k_spmv<9>
+        targs = re.sub(r",\s*(true|false)", "", targs)             # k_spmv<9, true, double> (compressed columns) -> k_spmv<9>
+        targs = re.sub(r",\s*double", "", targs).replace(", float", ",f32")   # single-precision transfer operators keep a tag
     return m.group(1) + targs
 
 
