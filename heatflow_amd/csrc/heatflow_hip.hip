@@ -41,6 +41,7 @@ inline size_t pad16(size_t b) { return (b + 15) & ~static_cast<size_t>(15); }
 // Upload the tables and size every buffer of the context for the mesh.
 int install_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int32_t* tri, const int32_t* tag, MeshTables& T) {
   free_batch(ctx);
+  proj_free(ctx);
   ctx->n = n; ctx->ne = ne; ctx->nnz = static_cast<int64_t>(T.colidx.size());
   ctx->nchunks = (n + RB - 1) / RB;
   ctx->nblk_a = (n + RBA - 1) / RBA;
@@ -331,7 +332,7 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_uprev); dev_free(&ctx->d_ustart);
   dev_free(&ctx->d_u); dev_free(&ctx->d_b); dev_free(&ctx->d_r); dev_free(&ctx->d_p); dev_free(&ctx->d_Ap);
-  free_batch(ctx); free_amg(ctx); free_responses(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
+  free_batch(ctx); free_amg(ctx); free_responses(ctx); proj_free(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
   dev_free(&ctx->d_M1); dev_free(&ctx->d_dinv1); dev_free(&ctx->d_gz); dev_free(&ctx->d_gr); dev_free(&ctx->d_bz); dev_free(&ctx->d_br);
   dev_free(&ctx->d_tmp); dev_free(&ctx->d_part_pAp); dev_free(&ctx->d_part_rz); dev_free(&ctx->d_part_zz);
   dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp);
@@ -514,7 +515,7 @@ int hf_set_precond(hf_ctx* ctx, int32_t kind, int32_t reuse) {
 
 int hf_set_start_vector(hf_ctx* ctx, int32_t kind) {
   if (!ctx) return HF_ERR_ARG;
-  if (kind < 0 || kind > 2) return fail(ctx, HF_ERR_ARG, "hf_set_start_vector: unknown kind %d", kind);
+  if (kind < 0 || kind > 3) return fail(ctx, HF_ERR_ARG, "hf_set_start_vector: unknown kind %d", kind);
   ctx->start_kind = kind;
   ctx->extrapolate = kind >= 1 ? 1 : 0;
   if (kind == 0) ctx->have_prev = false;
@@ -659,6 +660,7 @@ int hf_set_state(hf_ctx* ctx, const double* u) {
   HF_HIP(hipStreamSynchronize(ctx->stream));
   ctx->have_prev = false;
   ctx->g_hist = 0;       // the state no longer continues the recursion the boundary history belongs to
+  proj_clear(ctx, true);
   return HF_OK;
 }
 

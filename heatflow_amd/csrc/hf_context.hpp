@@ -117,12 +117,20 @@ struct hf_ctx {
   // hf_set_start_vector kind 2: boundary-response correction of the start vector.  Host copies of the last two
   // boundary vectors, an orthonormal set of directions seen in their second difference and, per direction d,
   // the device vector w = R d (A_hat w = -lift(d), w_B = d).
-  int start_kind = 2;
+  int start_kind = 3;
   std::vector<double> h_g0, h_g1;   // g^n, g^{n-1}
   int g_hist = 0;
   struct BcResponse { std::vector<double> dir; double* w = nullptr; };
   std::vector<BcResponse> resp;
   long long resp_solves = 0;
+  // hf_set_start_vector kind 3: Galerkin projection on the last solutions and the boundary responses (k_proj_*)
+  struct Proj {
+    double *V[10] = {nullptr}, *F[10] = {nullptr};   // slots 0..5: ring of (solution with zeroed Dirichlet entries, its right-hand side); 6..9: responses
+    bool used[10] = {false};
+    int next = 0, pending = -1;   // ring slot to overwrite next; slot whose Gram column is still to be computed
+    double *G = nullptr, *alpha = nullptr, *part = nullptr;
+    bool ready = false;
+  } proj;
   double *d_tmp = nullptr;
   // device: reductions
   double *d_part_pAp = nullptr, *d_part_rz = nullptr, *d_part_zz = nullptr, *d_part_bn = nullptr;

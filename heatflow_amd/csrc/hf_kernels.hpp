@@ -882,6 +882,157 @@ __global__ __launch_bounds__(TPB) void k_start_vector(int n, const double* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Start vector by Galerkin projection (hf_set_start_vector kind 3; Fischer 1998, "Projection techniques for
+// iterative solution of Ax = b with successive right-hand sides").  The free part of each of the last few
+// solutions u^k solves A_ff v = f^k with a known right-hand side, and so do the boundary responses w = R d.  The
+// start vector of the next solve is the combination of those vectors that is closest to the new solution in the
+// A-norm: G alpha = h with G_kl = V_k . F_l, h_k = V_k . f.  V_k holds u^k with its Dirichlet entries zeroed (so
+// every dot product runs over the free rows only), F_k the right-hand side b^k as it was.
+// ------------------------------------------------------------------------------------------
+constexpr int PROJ_MH = 6;                  // solutions kept
+constexpr int PROJ_MT = PROJ_MH + MAXRESP;  // + boundary responses
+struct ProjVecs { const double* V[PROJ_MT]; int slot[PROJ_MT]; int m; };
+
+// partial sums of h_k = V_k . f and (Fnew != null) of the Gram column g_k = V_k . Fnew, one pass over all vectors
+__global__ __launch_bounds__(TPB) void k_proj_dots(int n, ProjVecs a, const double* __restrict__ f, const double* __restrict__ Fnew,
+                                                   double* __restrict__ part /* [2 * PROJ_MT][MAXP] */) {
+  __shared__ double s4[4];
+  double ah[PROJ_MT], ag[PROJ_MT];
+#pragma unroll
+  for (int k = 0; k < PROJ_MT; ++k) { ah[k] = 0.0; ag[k] = 0.0; }
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+    const double fi = f ? f[i] : 0.0, gi = Fnew ? Fnew[i] : 0.0;
+#pragma unroll
+    for (int k = 0; k < PROJ_MT; ++k)
+      if (k < a.m) {
+        const double v = a.V[k][i];
+        ah[k] += v * fi;
+        ag[k] += v * gi;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < PROJ_MT; ++k)
+    if (k < a.m) {
+      const double th = block_sum(ah[k], s4), tg = block_sum(ag[k], s4);
+      if (threadIdx.x == 0) {
+        part[(2 * k) * MAXP + blockIdx.x] = th;
+        part[(2 * k + 1) * MAXP + blockIdx.x] = tg;
+      }
+    }
+}
+
+// One workgroup: finish the sums (a wavefront per sum, fixed order), store the Gram column of slot `jnew` (if >= 0),
+// and (do_solve) solve the scaled normal equations by symmetric elimination with diagonal pivoting (the matrix is
+// positive semi-definite, so its largest remaining entry sits on the diagonal); directions whose pivot falls below
+// 1e-12 of the first are left out (nearly dependent solutions).  alpha[slot] receives the coefficients (0 for
+// slots left out), alpha[PROJ_MT] the rank.
+__global__ __launch_bounds__(TPB) void k_proj_solve(int P, ProjVecs a, int jnew, int do_solve, double* __restrict__ part,
+                                                    double* __restrict__ G /* [PROJ_MT][PROJ_MT] by slot */, double* __restrict__ alpha) {
+  __shared__ double sh[PROJ_MT], sg[PROJ_MT];
+  __shared__ double A[PROJ_MT][PROJ_MT + 1], bb[PROJ_MT], dd[PROJ_MT], xx[PROJ_MT];
+  __shared__ int perm[PROJ_MT], piv, stop, rank_s;
+  __shared__ double pmax;
+  const int m = a.m, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int q = wave; q < 2 * m; q += TPB / 64) {           // sum q: partial array q of `part`
+    double v = 0.0;
+    for (int k0 = 0; k0 < P; k0 += 256) {
+      double e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int k = k0 + lane + 64 * u; e[u] = k < P ? part[q * MAXP + k] : 0.0; }
+      v += (e[0] + e[1]) + (e[2] + e[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) { if (q & 1) sg[q >> 1] = v; else sh[q >> 1] = v; }
+  }
+  __syncthreads();
+  if (jnew >= 0 && t < m) { G[a.slot[t] * PROJ_MT + jnew] = sg[t]; G[jnew * PROJ_MT + a.slot[t]] = sg[t]; }
+  if (!do_solve) return;
+  __syncthreads();                                          // the column just written is read below (same workgroup)
+  if (t < PROJ_MT + 1) alpha[t] = 0.0;
+  if (t < m) {
+    double gii = (jnew >= 0 && a.slot[t] == jnew) ? sg[t] : G[a.slot[t] * PROJ_MT + a.slot[t]];
+    const bool ok = gii > 0.0 && gii < 1e300;
+    dd[t] = ok ? 1.0 / sqrt(gii) : 0.0;
+    perm[t] = t;
+    xx[t] = 0.0;
+  }
+  __syncthreads();
+  const int i = t / PROJ_MT, j = t % PROJ_MT;
+  if (i < m && j < m) {
+    // entries of the new column come from shared memory (global writes of this launch are not re-read)
+    double gij;
+    if (jnew >= 0 && a.slot[j] == jnew) gij = sg[i];
+    else if (jnew >= 0 && a.slot[i] == jnew) gij = sg[j];
+    else gij = G[a.slot[i] * PROJ_MT + a.slot[j]];
+    const bool ok = dd[i] > 0.0 && dd[j] > 0.0;
+    A[i][j] = ok ? gij * dd[i] * dd[j] : (i == j ? 0.0 : 0.0);
+  }
+  if (t < m) bb[t] = sh[t] * dd[t];
+  if (t == 0) { rank_s = 0; stop = 0; }
+  __syncthreads();
+  for (int c = 0; c < m; ++c) {
+    if (t == 0) {
+      int pi = c;
+      double best = A[c][c];
+      for (int q = c + 1; q < m; ++q)
+        if (A[q][q] > best) { best = A[q][q]; pi = q; }
+      if (c == 0) pmax = best;
+      piv = pi;
+      stop = !(best > 1e-12 * pmax) || !(best > 0.0);
+    }
+    __syncthreads();
+    if (stop) break;
+    const int pv = piv;
+    if (pv != c) {                                          // symmetric interchange c <-> pv
+      if (t < m) { const double x0 = A[c][t]; A[c][t] = A[pv][t]; A[pv][t] = x0; }
+      __syncthreads();
+      if (t < m) { const double x0 = A[t][c]; A[t][c] = A[t][pv]; A[t][pv] = x0; }
+      if (t == 0) {
+        const double x0 = bb[c]; bb[c] = bb[pv]; bb[pv] = x0;
+        const int p0 = perm[c]; perm[c] = perm[pv]; perm[pv] = p0;
+      }
+      __syncthreads();
+    }
+    if (i > c && i < m && j > c && j < m) A[i][j] -= A[i][c] / A[c][c] * A[c][j];
+    if (i > c && i < m && j == c) bb[i] -= A[i][c] / A[c][c] * bb[c];
+    if (t == 0) rank_s = c + 1;
+    __syncthreads();
+  }
+  if (t != 0) return;
+  const int rank = rank_s;
+  for (int c = rank - 1; c >= 0; --c) {
+    double v = bb[c];
+    for (int q = c + 1; q < rank; ++q) v -= A[c][q] * xx[q];
+    xx[c] = v / A[c][c];
+  }
+  bool finite = true;
+  for (int c = 0; c < rank; ++c) finite = finite && (fabs(xx[c]) < 1e300);
+  if (!finite) return;                      // alpha = 0: the start vector falls back to the boundary values alone
+  for (int c = 0; c < rank; ++c) alpha[a.slot[perm[c]]] = xx[c] * dd[perm[c]];
+  alpha[PROJ_MT] = static_cast<double>(rank);
+}
+
+// u = sum_k alpha[slot_k] V_k   (Dirichlet entries come out zero: set_bc writes them afterwards)
+__global__ __launch_bounds__(TPB) void k_proj_combine(int n, ProjVecs a, const double* __restrict__ alpha, double* __restrict__ u) {
+  double c[PROJ_MT];
+#pragma unroll
+  for (int k = 0; k < PROJ_MT; ++k) c[k] = k < a.m ? alpha[a.slot[k]] : 0.0;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < PROJ_MT; ++k)
+      if (k < a.m) s += c[k] * a.V[k][i];
+    u[i] = s;
+  }
+}
+
+__global__ void k_zero_entries(int nq, const int32_t* __restrict__ idx, double* __restrict__ v) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq) v[idx[q]] = 0.0;
+}
+
 // Streaming read of two arrays with 16-byte loads (HF_K_STREAM_READ: the bandwidth ceiling SpMV is measured against)
 __global__ __launch_bounds__(TS) void k_stream_read(size_t n16a, const double2* __restrict__ a, size_t n16b,
                                                     const double2* __restrict__ b, double* __restrict__ sink) {

@@ -346,10 +346,71 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
   return HF_OK;
 }
 
+// forget the projection basis (new operator or new Dirichlet set); buffers are kept.  ring_only: a new state on the
+// same operator - the boundary responses stay valid, the solutions of the old trajectory are dropped.
+void proj_clear(hf_ctx* ctx, bool ring_only = false) {
+  for (int k = 0; k < (ring_only ? PROJ_MH : PROJ_MT); ++k) ctx->proj.used[k] = false;
+  ctx->proj.next = 0;
+  ctx->proj.pending = -1;
+}
+
+void proj_free(hf_ctx* ctx) {
+  proj_clear(ctx);
+  for (auto& v : ctx->proj.V) dev_free(&v);
+  for (auto& v : ctx->proj.F) dev_free(&v);
+  dev_free(&ctx->proj.G); dev_free(&ctx->proj.alpha); dev_free(&ctx->proj.part);
+  ctx->proj.ready = false;
+}
+
 void free_responses(hf_ctx* ctx) {
   for (auto& r : ctx->resp) dev_free(&r.w);
   ctx->resp.clear();
   ctx->g_hist = 0;
+  proj_clear(ctx);
+}
+
+int proj_ensure(hf_ctx* ctx) {
+  hf_ctx::Proj& Q = ctx->proj;
+  if (Q.ready) return HF_OK;
+  for (int k = 0; k < PROJ_MT; ++k) {
+    HF_TRY(dev_alloc(ctx, &Q.V[k], ctx->n));
+    HF_TRY(dev_alloc(ctx, &Q.F[k], ctx->n));
+  }
+  HF_TRY(dev_alloc(ctx, &Q.G, PROJ_MT * PROJ_MT));
+  HF_TRY(dev_alloc(ctx, &Q.alpha, PROJ_MT + 1));
+  HF_TRY(dev_alloc(ctx, &Q.part, static_cast<size_t>(2) * PROJ_MT * MAXP));
+  HF_HIP(hipMemsetAsync(Q.G, 0, sizeof(double) * PROJ_MT * PROJ_MT, ctx->stream));
+  Q.ready = true;
+  proj_clear(ctx);
+  return HF_OK;
+}
+
+ProjVecs proj_active(const hf_ctx* ctx) {
+  ProjVecs a{};
+  a.m = 0;
+  for (int k = 0; k < PROJ_MT; ++k)
+    if (ctx->proj.used[k]) { a.V[a.m] = ctx->proj.V[k]; a.slot[a.m] = k; ++a.m; }
+  return a;
+}
+
+// store (u with zeroed Dirichlet entries, right-hand side) in `slot`; its Gram column is computed by the next proj_column
+int proj_store(hf_ctx* ctx, int slot, const double* u, const double* rhs) {
+  hf_ctx::Proj& Q = ctx->proj;
+  HF_HIP(hipMemcpyAsync(Q.V[slot], u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+  HF_HIP(hipMemcpyAsync(Q.F[slot], rhs, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+  if (ctx->nbc > 0)
+    hipLaunchKernelGGL(k_zero_entries, dim3((ctx->nbc + 255) / 256), dim3(256), 0, ctx->stream, ctx->nbc, ctx->d_bc_dofs, Q.V[slot]);
+  Q.used[slot] = true;
+  return HF_OK;
+}
+
+// Gram column of `slot` (jnew) and, with `f`, the right-hand side h and the coefficients alpha
+void proj_column(hf_ctx* ctx, int slot, const double* f, bool solve) {
+  hf_ctx::Proj& Q = ctx->proj;
+  const ProjVecs a = proj_active(ctx);
+  hipLaunchKernelGGL(k_proj_dots, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, a, f, slot >= 0 ? Q.F[slot] : static_cast<const double*>(nullptr),
+                     Q.part);
+  hipLaunchKernelGGL(k_proj_solve, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, a, slot, solve ? 1 : 0, Q.part, Q.G, Q.alpha);
 }
 
 // w = R d for a new boundary direction d:  A_hat w = -lift(d) on the free rows, w_B = d  (one extra solve).
@@ -372,6 +433,11 @@ int solve_response(hf_ctx* ctx, const std::vector<double>& dir, int max_it, doub
   if (rc != HF_OK) { dev_free(&w); return rc; }
   ctx->resp_solves += 1;
   *w_out = w;
+  if (ctx->start_kind == 3 && ctx->proj.ready) {   // the response joins the projection basis: (w, its right-hand side)
+    const int slot = PROJ_MH + static_cast<int>(ctx->resp.size());
+    HF_TRY(proj_store(ctx, slot, w, ctx->d_b));
+    proj_column(ctx, slot, nullptr, false);
+  }
   return HF_OK;
 }
 
@@ -424,14 +490,21 @@ int step_device(hf_ctx* ctx, const double* g_host, const double* g_dev, double r
   const int nb = ctx->nbc;
   RespArgs ra{};
   ra.k = 0;
+  const bool projected = ctx->start_kind == 3;
+  if (projected) HF_TRY(proj_ensure(ctx));
   const bool hist_ok = nb > 0 && ctx->extrapolate && ctx->have_prev && ctx->g_hist >= 2;
   if (ctx->start_kind >= 2 && hist_ok) HF_TRY(prepare_response(ctx, g_host, max_it, &ra));
   if (nb > 0)
     HF_HIP(hipMemcpyAsync(ctx->d_g, g_dev ? g_dev : g_host, sizeof(double) * nb,
                           g_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-  // b = M u^n   (assemble_vector, run_with_diamond.py:476); with a previous step available the same
-  // pass writes the extrapolated start vector 2 u^n - u^{n-1}, and the three state buffers rotate
-  if (ctx->extrapolate && ctx->have_prev) {
+  if (projected) {
+    // b = M u^n, lifting, set_bc; then the start vector = A-norm projection of the new solution on the span of the last
+    // solutions and the boundary responses (kind 3)
+    launch_spmv<0>(ctx, ctx->d_M, ctx->d_u, ctx->d_b);
+    ctx->have_prev = true;
+  } else if (ctx->extrapolate && ctx->have_prev) {
+    // b = M u^n   (assemble_vector, run_with_diamond.py:476); with a previous step available the same
+    // pass writes the extrapolated start vector 2 u^n - u^{n-1}, and the three state buffers rotate
     launch_spmv<8>(ctx, ctx->d_M, ctx->d_u, ctx->d_b, nullptr, ctx->d_uprev, ctx->d_ustart);
     // u^{n-1} <- u^n, iterate <- start vector
     HF_HIP(hipMemcpyAsync(ctx->d_uprev, ctx->d_u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -454,6 +527,14 @@ int step_device(hf_ctx* ctx, const double* g_host, const double* g_dev, double r
     hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, ctx->d_g,
                        ctx->d_b, ctx->d_u);
   }
+  if (projected && proj_active(ctx).m > 0) {
+    hf_ctx::Proj& Q = ctx->proj;
+    proj_column(ctx, Q.pending, ctx->d_b, true);     // Gram column of the pair stored after the last step + h + alpha
+    Q.pending = -1;
+    hipLaunchKernelGGL(k_proj_combine, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, proj_active(ctx), Q.alpha, ctx->d_u);
+    if (nb > 0)
+      hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, ctx->d_g, ctx->d_b, ctx->d_u);
+  }
   const LinSys sys{ctx->d_A, ctx->d_dinv, ctx->d_u, ctx->d_b};
   const bool use_amg = ctx->precond == 1 && ctx->amg_ready;
   int rc = pcg_solve(ctx, sys, use_amg, rtol, atol, max_it, &ctx->pred_iters);
@@ -464,6 +545,12 @@ int step_device(hf_ctx* ctx, const double* g_host, const double* g_dev, double r
     ctx->amg_fallbacks += 1;
     int pred = 0;
     rc = pcg_solve(ctx, sys, false, rtol, atol, max_it, &pred);
+  }
+  if (rc == HF_OK && projected) {   // the new solution and its right-hand side join the projection basis
+    hf_ctx::Proj& Q = ctx->proj;
+    HF_TRY(proj_store(ctx, Q.next, ctx->d_u, ctx->d_b));
+    Q.pending = Q.next;
+    Q.next = (Q.next + 1) % PROJ_MH;
   }
   if (rc == HF_OK && nb > 0) {   // boundary history for the next step's second difference
     ctx->h_g1.swap(ctx->h_g0);

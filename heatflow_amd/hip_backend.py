@@ -252,8 +252,9 @@ class HeatflowHIP:
         """PC_JACOBI (0) or PC_AMG (1); call before assemble()."""
         self._check(self._lib.hf_set_precond(self._ctx, int(kind), 1 if reuse else 0))
 
-    def set_start_vector(self, kind=2):
-        """0: u^n, 1: 2u^n - u^{n-1}, 2 (default): that + response to the boundary values' second difference."""
+    def set_start_vector(self, kind=3):
+        """0: u^n, 1: 2u^n - u^{n-1}, 2: that + response to the boundary values' second difference, 3 (default):
+        A-norm projection on the last solutions and the boundary responses."""
         self._check(self._lib.hf_set_start_vector(self._ctx, int(kind)))
 
     def response_solves(self):

@@ -657,11 +657,12 @@ def test_start_vector_kinds_same_answer_fewer_iterations(hip, precond, case_with
     """hf_set_start_vector: the converged field does not depend on the start vector; the boundary-response
     correction (kind 2) costs one extra solve per operator (the heated line's profile is the only direction
     the second difference of the boundary values ever has) and needs fewer iterations than plain
-    extrapolation (kind 1), which needs fewer than starting from u^n (kind 0)."""
+    extrapolation (kind 1), which needs fewer than starting from u^n (kind 0); the A-norm projection on the last
+    solutions and that response (kind 3, the default) contains both as special cases and needs fewest."""
     cfg, stack, mesh = case_with_diamond_small
     nsteps = 40
     out = {}
-    for kind in (0, 1, 2):
+    for kind in (0, 1, 2, 3):
         prob = make_problem(cfg, stack, mesh, precond=precond)
         try:
             prob.backend.set_start_vector(kind)
@@ -669,16 +670,18 @@ def test_start_vector_kinds_same_answer_fewer_iterations(hip, precond, case_with
             out[kind] = (prob.state(), int(np.sum(iters)), prob.backend.response_solves())
         finally:
             prob.close()
-    for kind in (1, 2):
+    for kind in (1, 2, 3):
         assert np.abs(out[kind][0] - out[0][0]).max() <= 2e-5, kind
-    assert out[0][2] == 0 and out[1][2] == 0 and out[2][2] == 1
-    assert out[2][1] < out[1][1] <= out[0][1], {k: v[1] for k, v in out.items()}
+    assert out[0][2] == 0 and out[1][2] == 0 and out[2][2] == 1 and out[3][2] == 1
+    assert out[3][1] < out[2][1] < out[1][1] <= out[0][1], {k: v[1] for k, v in out.items()}
+    print({k: v[1] for k, v in out.items()})
     if precond == 1:   # multigrid-PCG contracts at a fixed rate per iteration: a 30x smaller start residual shows
         assert out[2][1] <= 0.95 * out[1][1], {k: v[1] for k, v in out.items()}
+        assert out[3][1] <= 0.92 * out[2][1], {k: v[1] for k, v in out.items()}
     prob2 = make_problem(cfg, stack, mesh, precond=precond)
     try:
         with pytest.raises(ValueError):
-            prob2.backend.set_start_vector(3)
+            prob2.backend.set_start_vector(4)
     finally:
         prob2.close()
 
@@ -1048,7 +1051,7 @@ def test_batched_time_loop_with_a_shared_operator_matches_single_runs(hip, preco
         for j in range(nv):
             assert np.abs(be.batch_get_state(j) - singles[j][0]).max() <= 1e-5
             assert np.abs(samples[:, j, :] - singles[j][1]).max() <= 1e-5
-            assert iters[:, j].max() >= 3 and abs(int(iters[:, j].sum()) - int(singles[j][2].sum())) <= 0.15 * int(singles[j][2].sum()) + nsteps   # the batch starts from 2u^n - u^(n-1) without the boundary-response term
+            assert iters[:, j].max() >= 3 and int(iters[:, j].sum()) <= 1.5 * int(singles[j][2].sum()) + nsteps   # the batch starts from 2u^n - u^(n-1), the single run from the projected start vector
         assert np.abs(singles[0][0] - singles[3][0]).max() > 1.0
         be.batch_end()
         # the context still steps on its own after the batch
