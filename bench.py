@@ -17,7 +17,7 @@ refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
   broadcasts over RCCL together with its tag map; no data-path collective.  value = all ranks' DOF-updates /
   max-over-ranks time ("weak" scaling).
 * workload ``sweep64`` (BASELINE C5): 64 kappa_sample values (parameter_sweep.get_k_values(count=64)) at stock
-  mesh size, point i -> rank i mod world, batches of 8 points per time loop (hf_batch_*), 4 loops in flight per rank; K = time steps per point (default: the
+  mesh size, point i -> rank i mod world, batches of 8 points per time loop (hf_batch_*), 2 loops in flight per rank; K = time steps per point (default: the
   config's 100), W = untimed steps every solver session runs first.  value = 64*n*K / wall of the point loop
   (max over ranks), "strong" scaling (the 64 points are fixed).  The same sweep is also run as a side
   measurement of the default workload (``config.sweep64``; ``--sweep-points 0`` skips it).
@@ -54,7 +54,7 @@ MESH_SCALE = 0.43          # all `mesh:` values x 0.43 -> 1.04 M nodes (within +
 HBM_SCALE = 0.1075         # -> 16 M nodes: matrix 1.3 GB, vectors 128 MB each, nothing stays in the 256 MiB Infinity Cache
 SWEEP_POINTS = 64          # BASELINE C5
 SWEEP_BATCH = 8            # points per batched time loop (hf_batch_*): columns of one multi-vector PCG
-SWEEP_CONCURRENT = 4       # time loops in flight per rank (64 points on one GPU, batch 8: 1/2/4 in flight = 5.3/6.3/6.5e8 DOF-updates/s; unbatched, 6 in flight: 4.5e8)
+SWEEP_CONCURRENT = 2       # time loops in flight per rank (64 points on one GPU in batches of 8: 1/2/4 in flight = 5.8/6.9/5.6-6.5e8 DOF-updates/s; unbatched, 6 in flight: 4.5e8)
 
 
 def parse_args(argv=None):

@@ -779,6 +779,16 @@ int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t operator_kind) {
   HF_HIP(hipMemsetAsync(B.scal, 0, sizeof(Scal) * nv, ctx->stream));
   HF_TRY(dev_alloc(ctx, &B.red, 1));
   HF_HIP(hipMemsetAsync(B.red, 0, sizeof(BRed), ctx->stream));
+  for (int k = 0; k < PROJ_MH; ++k) {
+    HF_TRY(dev_alloc(ctx, &B.pV[k], vec));
+    HF_TRY(dev_alloc(ctx, &B.pF[k], vec));
+    B.pused[k] = false;
+  }
+  HF_TRY(dev_alloc(ctx, &B.pG, static_cast<size_t>(nv) * PROJ_MT * PROJ_MT));
+  HF_TRY(dev_alloc(ctx, &B.palpha, static_cast<size_t>(nv) * (PROJ_MT + 1)));
+  HF_TRY(dev_alloc(ctx, &B.ppart, static_cast<size_t>(nv) * 2 * PROJ_MT * MAXP));
+  HF_HIP(hipMemsetAsync(B.pG, 0, sizeof(double) * nv * PROJ_MT * PROJ_MT, ctx->stream));
+  B.pnext = 0; B.ppending = -1;
   if (hipHostMalloc(reinterpret_cast<void**>(&B.h_scal), sizeof(Scal) * nv) != hipSuccess) return fail(ctx, HF_ERR_ALLOC, "hipHostMalloc failed");
   const int rpb = TPB / nv;
   B.Pb = static_cast<int>(std::min<size_t>((n + rpb - 1) / rpb, MAXP));
@@ -836,6 +846,8 @@ int hf_batch_load_column(hf_ctx* ctx, int32_t j) {
   HF_HIP(hipGetLastError());
   HF_HIP(hipStreamSynchronize(ctx->stream));
   B.loaded |= 1u << j;
+  for (bool& u_ : B.pused) u_ = false;     // stored solutions belong to the operators they were computed with
+  B.pnext = 0; B.ppending = -1;
   return HF_OK;
 }
 
@@ -888,6 +900,8 @@ int hf_batch_set_affine(hf_ctx* ctx, int32_t n_tags, const int32_t* tags, const 
   HF_HIP(hipGetLastError());
   HF_HIP(hipStreamSynchronize(ctx->stream));
   B.loaded = 1;
+  for (bool& u_ : B.pused) u_ = false;
+  B.pnext = 0; B.ppending = -1;
   return HF_OK;
 }
 
@@ -902,6 +916,8 @@ int hf_batch_set_state(hf_ctx* ctx, int32_t j, const double* u) {
   HF_HIP(hipGetLastError());
   HF_HIP(hipStreamSynchronize(ctx->stream));
   B.have_prev = false;
+  for (bool& u_ : B.pused) u_ = false;     // a new state: the old trajectory's solutions leave every column's basis
+  B.pnext = 0; B.ppending = -1;
   return HF_OK;
 }
 

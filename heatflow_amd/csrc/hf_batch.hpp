@@ -380,6 +380,64 @@ __global__ void kb_set_bc(int nbc, const int32_t* __restrict__ dofs, const doubl
   u[o] = g[static_cast<size_t>(q) * NV + j];
 }
 
+// Projection start vector (k_proj_* in hf_kernels.hpp) for NV interleaved columns: per column the partial sums of
+// h_k = V_k . f and of the Gram column g_k = V_k . Fnew; layout part[(j * 2 PROJ_MT + 2k + s) * MAXP + workgroup]
+template <int NV>
+__global__ __launch_bounds__(TPB) void kb_proj_dots(int n, ProjVecs a, const double* __restrict__ f, const double* __restrict__ Fnew,
+                                                    double* __restrict__ part) {
+  __shared__ double sw[4 * NV];
+  constexpr int RPB = TPB / NV;
+  const int j = threadIdx.x % NV, rl = threadIdx.x / NV;
+  double ah[PROJ_MH], ag[PROJ_MH];
+#pragma unroll
+  for (int k = 0; k < PROJ_MH; ++k) { ah[k] = 0.0; ag[k] = 0.0; }
+  const int nrb = (n + RPB - 1) / RPB;
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    const int row = rb * RPB + rl;
+    if (row >= n) continue;
+    const size_t o = static_cast<size_t>(row) * NV + j;
+    const double fi = f[o], gi = Fnew ? Fnew[o] : 0.0;
+#pragma unroll
+    for (int k = 0; k < PROJ_MH; ++k)
+      if (k < a.m) {
+        const double v = a.V[k][o];
+        ah[k] += v * fi;
+        ag[k] += v * gi;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < PROJ_MH; ++k)
+    if (k < a.m) {
+      const double th = block_colsum<NV>(ah[k], sw), tg = block_colsum<NV>(ag[k], sw);
+      if (rl == 0) {
+        part[(static_cast<size_t>(j) * 2 * PROJ_MT + 2 * k) * MAXP + blockIdx.x] = th;
+        part[(static_cast<size_t>(j) * 2 * PROJ_MT + 2 * k + 1) * MAXP + blockIdx.x] = tg;
+      }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(TPB) void kb_proj_combine(int n, ProjVecs a, const double* __restrict__ alpha /* [NV][PROJ_MT + 1] */,
+                                                       double* __restrict__ u) {
+  const int j = threadIdx.x % NV;
+  double c[PROJ_MH];
+#pragma unroll
+  for (int k = 0; k < PROJ_MH; ++k) c[k] = k < a.m ? alpha[j * (PROJ_MT + 1) + a.slot[k]] : 0.0;
+  for (size_t q = static_cast<size_t>(blockIdx.x) * TPB + threadIdx.x; q < static_cast<size_t>(n) * NV; q += static_cast<size_t>(gridDim.x) * TPB) {
+    double s = 0.0;                          // TPB is a multiple of NV: a thread stays with its column
+#pragma unroll
+    for (int k = 0; k < PROJ_MH; ++k)
+      if (k < a.m) s += c[k] * a.V[k][q];
+    u[q] = s;
+  }
+}
+
+template <int NV>
+__global__ void kb_zero_bc(int nbc, const int32_t* __restrict__ dofs, double* __restrict__ v) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nbc * NV) v[static_cast<size_t>(dofs[t / NV]) * NV + t % NV] = 0.0;
+}
+
 template <int NV>
 __global__ void kb_gather(int ns, const int32_t* __restrict__ idx, const double* __restrict__ u, double* __restrict__ out /* [j][ns] */) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,6 +464,9 @@ void free_batch(hf_ctx* ctx) {
   dev_free(&B.u); dev_free(&B.uprev); dev_free(&B.ustart); dev_free(&B.b); dev_free(&B.r); dev_free(&B.p); dev_free(&B.Ap);
   dev_free(&B.z); dev_free(&B.z2); dev_free(&B.tmp);
   dev_free(&B.part_pAp); dev_free(&B.part_rz); dev_free(&B.part_zz); dev_free(&B.part_bn); dev_free(&B.scal); dev_free(&B.red);
+  for (auto& v : B.pV) dev_free(&v);
+  for (auto& v : B.pF) dev_free(&v);
+  dev_free(&B.pG); dev_free(&B.palpha); dev_free(&B.ppart);
   for (auto& L : B.lev) { dev_free(&L.x); dev_free(&L.cat); if (L.own_b) dev_free(&L.b); }
   B.lev.clear();
   if (B.h_scal) { (void)hipHostFree(B.h_scal); B.h_scal = nullptr; }
@@ -578,20 +639,22 @@ struct BatchOps {
     return HF_OK;
   }
 
-  // one time step of all columns to the boundary values g_dev (n_bc x NV, interleaved, on the device)
+  static ProjVecs proj_active(const hf_ctx::Batch& B) {
+    ProjVecs a{};
+    a.m = 0;
+    for (int k = 0; k < PROJ_MH; ++k)
+      if (B.pused[k]) { a.V[a.m] = B.pV[k]; a.slot[a.m] = k; ++a.m; }
+    return a;
+  }
+
+  // one time step of all columns to the boundary values g_dev (n_bc x NV, interleaved, on the device).  Start vector:
+  // per column the A-norm projection of the new solution on the span of its last solutions (kind 3 of the
+  // single-column loop, without the boundary responses)
   static int step(hf_ctx* ctx, const double* g_dev, double rtol, double atol, int max_it) {
     hf_ctx::Batch& B = ctx->batch;
     const int nb = ctx->nbc;
     const size_t vec = sizeof(double) * static_cast<size_t>(ctx->n) * NV;
-    if (B.have_prev) {
-      spmv<8>(ctx, ctx->d_M, B.u, B.b, nullptr, B.uprev, B.ustart);
-      HF_HIP(hipMemcpyAsync(B.uprev, B.u, vec, hipMemcpyDeviceToDevice, ctx->stream));
-      HF_HIP(hipMemcpyAsync(B.u, B.ustart, vec, hipMemcpyDeviceToDevice, ctx->stream));
-    } else {
-      spmv<0>(ctx, ctx->d_M, B.u, B.b);
-      HF_HIP(hipMemcpyAsync(B.uprev, B.u, vec, hipMemcpyDeviceToDevice, ctx->stream));
-      B.have_prev = true;
-    }
+    spmv<0>(ctx, ctx->d_M, B.u, B.b);
     if (nb > 0) {
       if (ctx->nlift_rows > 0) {
         const int thr = ctx->nlift_rows * NV;
@@ -600,8 +663,29 @@ struct BatchOps {
       }
       hipLaunchKernelGGL((kb_set_bc<NV>), dim3((nb * NV + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, g_dev, B.b, B.u);
     }
+    const ProjVecs act = proj_active(B);
+    if (act.m > 0) {
+      hipLaunchKernelGGL((kb_proj_dots<NV>), dim3(B.Pb), dim3(TPB), 0, ctx->stream, ctx->n, act, B.b,
+                         B.ppending >= 0 ? B.pF[B.ppending] : static_cast<const double*>(nullptr), B.ppart);
+      hipLaunchKernelGGL(k_proj_solve, dim3(NV), dim3(TPB), 0, ctx->stream, B.Pb, act, B.ppending, 1, B.ppart, B.pG, B.palpha);
+      B.ppending = -1;
+      hipLaunchKernelGGL((kb_proj_combine<NV>), dim3(B.Pb), dim3(TPB), 0, ctx->stream, ctx->n, act, B.palpha, B.u);
+      if (nb > 0)
+        hipLaunchKernelGGL((kb_set_bc<NV>), dim3((nb * NV + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, g_dev, B.b, B.u);
+    }
     const bool use_amg = ctx->precond == 1 && ctx->amg_ready;
-    return pcg(ctx, use_amg, rtol, atol, max_it);
+    const int rc = pcg(ctx, use_amg, rtol, atol, max_it);
+    if (rc == HF_OK) {   // (solution with zeroed Dirichlet entries, right-hand side) joins every column's basis
+      const int slot = B.pnext;
+      HF_HIP(hipMemcpyAsync(B.pV[slot], B.u, vec, hipMemcpyDeviceToDevice, ctx->stream));
+      HF_HIP(hipMemcpyAsync(B.pF[slot], B.b, vec, hipMemcpyDeviceToDevice, ctx->stream));
+      if (nb > 0)
+        hipLaunchKernelGGL((kb_zero_bc<NV>), dim3((nb * NV + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, B.pV[slot]);
+      B.pused[slot] = true;
+      B.ppending = slot;
+      B.pnext = (slot + 1) % PROJ_MH;
+    }
+    return rc;
   }
 };
 

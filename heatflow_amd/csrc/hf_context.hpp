@@ -192,6 +192,10 @@ struct hf_ctx {
     std::vector<BatchLevel> lev;
     int Pb = 0, pred_iters = 0;
     bool have_prev = false;
+    // projection start vector per column: ring of (solutions with zeroed Dirichlet entries, right-hand sides)
+    double *pV[6] = {nullptr}, *pF[6] = {nullptr}, *pG = nullptr, *palpha = nullptr, *ppart = nullptr;
+    bool pused[6] = {false};
+    int pnext = 0, ppending = -1;
     unsigned loaded = 0;         // bit j: column j's operator has been loaded (percol)
   } batch;
   // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch

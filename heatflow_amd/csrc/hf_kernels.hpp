@@ -933,6 +933,10 @@ __global__ __launch_bounds__(TPB) void k_proj_solve(int P, ProjVecs a, int jnew,
   __shared__ double A[PROJ_MT][PROJ_MT + 1], bb[PROJ_MT], dd[PROJ_MT], xx[PROJ_MT];
   __shared__ int perm[PROJ_MT], piv, stop, rank_s;
   __shared__ double pmax;
+  // batched loop: one workgroup per column, each with its own partial sums, Gram matrix and coefficients
+  part += static_cast<size_t>(blockIdx.x) * 2 * PROJ_MT * MAXP;
+  G += blockIdx.x * PROJ_MT * PROJ_MT;
+  alpha += blockIdx.x * (PROJ_MT + 1);
   const int m = a.m, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   for (int q = wave; q < 2 * m; q += TPB / 64) {           // sum q: partial array q of `part`
     double v = 0.0;
