@@ -41,6 +41,7 @@ inline size_t pad16(size_t b) { return (b + 15) & ~static_cast<size_t>(15); }
 // Upload the tables and size every buffer of the context for the mesh.
 int install_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int32_t* tri, const int32_t* tag, MeshTables& T) {
   free_batch(ctx);
+  free_batch_state(ctx->fluxb);
   proj_free(ctx);
   ctx->n = n; ctx->ne = ne; ctx->nnz = static_cast<int64_t>(T.colidx.size());
   ctx->nchunks = (n + RB - 1) / RB;
@@ -332,7 +333,7 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_uprev); dev_free(&ctx->d_ustart);
   dev_free(&ctx->d_u); dev_free(&ctx->d_b); dev_free(&ctx->d_r); dev_free(&ctx->d_p); dev_free(&ctx->d_Ap);
-  free_batch(ctx); free_amg(ctx); free_responses(ctx); proj_free(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
+  free_batch(ctx); free_batch_state(ctx->fluxb); free_amg(ctx); free_responses(ctx); proj_free(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
   dev_free(&ctx->d_M1); dev_free(&ctx->d_dinv1); dev_free(&ctx->d_gz); dev_free(&ctx->d_gr); dev_free(&ctx->d_bz); dev_free(&ctx->d_br);
   dev_free(&ctx->d_tmp); dev_free(&ctx->d_part_pAp); dev_free(&ctx->d_part_rz); dev_free(&ctx->d_part_zz);
   dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp);
@@ -575,6 +576,30 @@ int hf_flux_setup(hf_ctx* ctx) {
   HF_HIP(hipMemsetAsync(ctx->d_gr, 0, sizeof(double) * n, ctx->stream));
   HF_HIP(hipGetLastError());
   HF_HIP(hipStreamSynchronize(ctx->stream));
+  // two-column PCG state: both gradient components share every pass over M_r(1) (Jacobi-PCG of the batched loop)
+  {
+    hf_ctx::Batch& F = ctx->fluxb;
+    free_batch_state(F);
+    const size_t vec = static_cast<size_t>(n) * 2;
+    for (double** v : {&F.u, &F.b, &F.r, &F.p, &F.Ap, &F.z}) {
+      HF_TRY(dev_alloc(ctx, v, vec));
+      HF_HIP(hipMemsetAsync(*v, 0, sizeof(double) * vec, ctx->stream));
+    }
+    HF_TRY(dev_alloc(ctx, &F.part_pAp, 2 * static_cast<size_t>(MAXP)));
+    HF_TRY(dev_alloc(ctx, &F.part_rz, 4 * static_cast<size_t>(MAXP)));
+    HF_TRY(dev_alloc(ctx, &F.part_zz, 2 * static_cast<size_t>(MAXP)));
+    HF_TRY(dev_alloc(ctx, &F.part_bn, 2 * static_cast<size_t>(MAXP)));
+    HF_TRY(dev_alloc(ctx, &F.scal, 2));
+    HF_TRY(dev_alloc(ctx, &F.red, 1));
+    HF_HIP(hipMemsetAsync(F.scal, 0, sizeof(Scal) * 2, ctx->stream));
+    HF_HIP(hipMemsetAsync(F.red, 0, sizeof(BRed), ctx->stream));
+    if (hipHostMalloc(reinterpret_cast<void**>(&F.h_scal), sizeof(Scal) * 2) != hipSuccess) return fail(ctx, HF_ERR_ALLOC, "hipHostMalloc failed");
+    F.Pb = static_cast<int>(std::min<size_t>((static_cast<size_t>(n) + 127) / 128, MAXP));
+    if (F.Pb >= 64) F.Pb &= ~7;
+    F.nv = 2; F.opk = 0; F.pred_iters = 0;
+    F.sysA = ctx->d_M1; F.sysDinv = ctx->d_dinv1;
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+  }
   ctx->flux_ready = true;
   ctx->pred_flux[0] = ctx->pred_flux[1] = 0;
   return HF_OK;
@@ -585,6 +610,7 @@ int hf_flux_solve(hf_ctx* ctx, int32_t components, double rtol, int32_t max_it, 
   if (!ctx->flux_ready) return fail(ctx, HF_ERR_STATE, "hf_flux_solve before hf_flux_setup");
   if (max_it <= 0 || rtol < 0 || components < 0 || components > 3) return fail(ctx, HF_ERR_ARG, "hf_flux_solve: bad arguments");
   HF_HIP(hipSetDevice(ctx->dev));
+  const bool both = components == 3 && ctx->rg_ok && ctx->fluxb.nv == 2;
   if (ctx->rg_ok) {
     const int capd = ctx->rg_max_dict;
     const size_t sm = static_cast<size_t>(capd) * 16 + static_cast<size_t>(capd + (capd & 1)) * 8 + (RBA + 4) * 4 +
@@ -592,11 +618,29 @@ int hf_flux_solve(hf_ctx* ctx, int32_t components, double rtol, int32_t max_it, 
     const int grid = std::min(ctx->nblk_a, 2048);
     hipLaunchKernelGGL(k_grad_rows, dim3(grid), dim3(RBA), sm, ctx->stream, ctx->nblk_a, capd, ctx->d_rg_hdr,
                        reinterpret_cast<const uint4*>(ctx->d_rg_ell), reinterpret_cast<const uint4*>(ctx->d_rg_cid), ctx->d_rg_zrb,
-                       ctx->d_rg_dict, ctx->d_rowptr, ctx->d_u, ctx->d_bz, ctx->d_br);
+                       ctx->d_rg_dict, ctx->d_rowptr, ctx->d_u, both ? ctx->fluxb.b : ctx->d_bz, both ? ctx->fluxb.b + 1 : ctx->d_br,
+                       both ? 2 : 1);
   } else {
     HF_TRY(ensure_owner_lists(ctx));
     hipLaunchKernelGGL(k_grad_rhs, dim3(ctx->nblk_a), dim3(RBA), 0, ctx->stream, ctx->n, ctx->d_blk_eptr, ctx->d_blk_ent,
                        ctx->d_zr, ctx->d_u, ctx->d_bz, ctx->d_br);
+  }
+  HF_HIP(hipGetLastError());
+  if (both) {
+    // both components as the two interleaved columns of one Jacobi-PCG on M_r(1): every pass over the matrix serves
+    // both (reference: one 2n x 2n vector-P1 solve, run_no_diamond.py:479-489, 544-550); warm start = last projection
+    std::swap(ctx->batch, ctx->fluxb);
+    const int rc = BatchOps<2, OP_SHARED>::pcg(ctx, false, rtol, 0.0, max_it);
+    const int it0 = ctx->batch.h_scal[0].iters, it1 = ctx->batch.h_scal[1].iters;
+    std::swap(ctx->batch, ctx->fluxb);
+    if (iters) { iters[0] = it0; iters[1] = it1; }
+    ctx->flux_valid = 0;
+    if (rc != HF_OK) return rc;
+    hipLaunchKernelGGL(kb_get_column, dim3(1024), dim3(256), 0, ctx->stream, static_cast<size_t>(ctx->n), 2, 0, ctx->fluxb.u, ctx->d_gz);
+    hipLaunchKernelGGL(kb_get_column, dim3(1024), dim3(256), 0, ctx->stream, static_cast<size_t>(ctx->n), 2, 1, ctx->fluxb.u, ctx->d_gr);
+    HF_HIP(hipGetLastError());
+    ctx->flux_valid = 3;
+    return HF_OK;
   }
   if (iters) iters[0] = iters[1] = 0;
   ctx->flux_valid = 0;

@@ -458,8 +458,7 @@ __global__ void kb_get_column(size_t n, int nv, int j, const double* __restrict_
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-void free_batch(hf_ctx* ctx) {
-  hf_ctx::Batch& B = ctx->batch;
+void free_batch_state(hf_ctx::Batch& B) {
   dev_free(&B.A); dev_free(&B.A1); dev_free(&B.dinv); dev_free(&B.lift_val); dev_free(&B.lift1); dev_free(&B.g);
   dev_free(&B.u); dev_free(&B.uprev); dev_free(&B.ustart); dev_free(&B.b); dev_free(&B.r); dev_free(&B.p); dev_free(&B.Ap);
   dev_free(&B.z); dev_free(&B.z2); dev_free(&B.tmp);
@@ -471,7 +470,10 @@ void free_batch(hf_ctx* ctx) {
   B.lev.clear();
   if (B.h_scal) { (void)hipHostFree(B.h_scal); B.h_scal = nullptr; }
   B.nv = 0;
+  B.sysA = B.sysDinv = nullptr;
 }
+
+void free_batch(hf_ctx* ctx) { free_batch_state(ctx->batch); }
 
 template <int NV, int VMODE, typename VT>
 void blaunch_csr_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y) {
@@ -503,7 +505,7 @@ struct BatchOps {
   static BOp Aop(hf_ctx* c) {
     const hf_ctx::Batch& B = c->batch;
     BOp o{};
-    o.v0 = OPK == OP_PERCOL ? B.A : c->d_A;
+    o.v0 = B.sysA ? B.sysA : (OPK == OP_PERCOL ? B.A : c->d_A);
     o.v1 = B.A1;
     for (int j = 0; j < 8; ++j) o.delta[j] = B.delta[j];
     return o;
@@ -517,7 +519,7 @@ struct BatchOps {
     return o;
   }
   static const double* Avals(hf_ctx* c) { return c->d_A; }   // tag: "the system operator" (any pointer but d_M)
-  static const double* Dinv(hf_ctx* c) { return DPC ? c->batch.dinv : c->d_dinv; }
+  static const double* Dinv(hf_ctx* c) { return c->batch.sysDinv ? c->batch.sysDinv : (DPC ? c->batch.dinv : c->d_dinv); }
 
   template <int MODE>
   static void spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr, const double* bvec = nullptr,

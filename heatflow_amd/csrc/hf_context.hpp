@@ -180,6 +180,7 @@ struct hf_ctx {
   struct Batch {
     int nv = 0;                  // 0: no batch open
     int opk = 0;                 // fine operator of the columns: 0 shared (ctx->d_A), 1 one per column, 2 affine A + d_j A1
+    const double *sysA = nullptr, *sysDinv = nullptr;   // shared operator other than ctx->d_A (the flux projection's mass matrix)
     double *A = nullptr, *dinv = nullptr, *lift_val = nullptr;            // per-column operator data (opk 1; dinv also opk 2)
     double *A1 = nullptr, *lift1 = nullptr;                               // affine part and its lifting values (opk 2)
     double delta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -198,6 +199,7 @@ struct hf_ctx {
     int pnext = 0, ppending = -1;
     unsigned loaded = 0;         // bit j: column j's operator has been loaded (percol)
   } batch;
+  Batch fluxb;                   // two-column state of the read-flux projection (both components in one PCG), swapped into `batch` while it runs
   // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;

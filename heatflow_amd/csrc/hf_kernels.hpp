@@ -364,7 +364,8 @@ __global__ __launch_bounds__(RBA) void k_assemble_rows(int nblk, int cap /* slab
 __global__ __launch_bounds__(RBA) void k_grad_rows(int nblk, int capd, const int4* __restrict__ hdr, const uint4* __restrict__ ell,
                                                    const uint4* __restrict__ cid16, const double2* __restrict__ zrb,
                                                    const int32_t* __restrict__ dict, const int32_t* __restrict__ rowptr,
-                                                   const double* __restrict__ u, double* __restrict__ bz, double* __restrict__ br) {
+                                                   const double* __restrict__ u, double* __restrict__ bz, double* __restrict__ br,
+                                                   int stride /* 1: two arrays; 2: bz = out, br = out + 1 interleaved */) {
   extern __shared__ double smem[];
   double2* sXd = reinterpret_cast<double2*>(smem);
   double* sU = smem + 2 * capd;
@@ -404,8 +405,8 @@ __global__ __launch_bounds__(RBA) void k_grad_rows(int nblk, int capd, const int
           ar += gr * wgt;
         }
       }
-      bz[blk * RBA + t] = az;
-      br[blk * RBA + t] = ar;
+      bz[static_cast<size_t>(blk * RBA + t) * stride] = az;
+      br[static_cast<size_t>(blk * RBA + t) * stride] = ar;
     }
     __syncthreads();
   }

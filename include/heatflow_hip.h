@@ -200,9 +200,10 @@ int hf_batch_end(hf_ctx* ctx);
 /* Read-flux projection of run_no_diamond (reference run_no_diamond.py:471-491 set-up, :543-550 per
  * step): grad_smooth = L2 projection of grad(T) onto vector P1 with weight r.  hf_flux_setup
  * assembles the unit-coefficient r-weighted mass matrix on the mesh's pattern (once per mesh);
- * hf_flux_project projects the CURRENT state: one Jacobi-PCG solve per component (z, r; the 2n x 2n
- * system of the reference is block diagonal, so the components decouple exactly; same stopping rule as
- * hf_step), results copied to grad_z / grad_r (n values each).  A NULL output skips that component's
+ * hf_flux_project projects the CURRENT state: the 2n x 2n system of the reference is block diagonal, so the
+ * components decouple exactly into two scalar solves with M_r(1); when both are wanted they run as the two
+ * interleaved columns of ONE Jacobi-PCG (every pass over the matrix serves both; per column the stopping rule
+ * of hf_step), a single wanted component is solved on its own; results copied to grad_z / grad_r (n values each).  A NULL output skips that component's
  * solve altogether (run_no_diamond's outputs only use d/dr, :553-566).  iters = 2 entries (may be NULL).
  * hf_flux_solve does the same without any copy (components: bit 0 = z, bit 1 = r); hf_flux_sample then
  * reads the projected gradient at n_s nodes (either output may be NULL) - what the band / axis averages
