@@ -60,7 +60,8 @@ __device__ __forceinline__ double col_partials(const double* __restrict__ part /
 
 // one workgroup per (array, column): 256 threads add the column's P partials in a fixed order
 __global__ __launch_bounds__(TPB) void kb_reduce(int P, int nv, const double* __restrict__ part_a, double* __restrict__ out_a,
-                                                 const double* __restrict__ part_b, double* __restrict__ out_b) {
+                                                 const double* __restrict__ part_b, double* __restrict__ out_b,
+                                                 Scal* __restrict__ test /* non-null: out_a is (D^-1 r)^2 - mark converged columns done */) {
   __shared__ double s4[4];
   const int j = blockIdx.x % nv;
   const bool second = blockIdx.x >= nv;
@@ -75,7 +76,10 @@ __global__ __launch_bounds__(TPB) void kb_reduce(int P, int nv, const double* __
 #pragma unroll
   for (int u = 0; u < MAXP / TPB; ++u) v += e[u];
   const double t = block_sum(v, s4);
-  if (threadIdx.x == 0) (second ? out_b : out_a)[j] = t;
+  if (threadIdx.x == 0) {
+    (second ? out_b : out_a)[j] = t;
+    if (test != nullptr && !second && test[j].done == 0 && t <= test[j].tol2) { test[j].zz = t; test[j].done = 1; }
+  }
 }
 
 // The fine operator of column j of a batch:
@@ -537,8 +541,9 @@ struct BatchOps {
     }
   }
 
-  static void reduce(hf_ctx* c, const double* part_a, double* out_a, const double* part_b = nullptr, double* out_b = nullptr) {
-    hipLaunchKernelGGL(kb_reduce, dim3(part_b ? 2 * NV : NV), dim3(TPB), 0, c->stream, c->batch.Pb, NV, part_a, out_a, part_b, out_b);
+  static void reduce(hf_ctx* c, const double* part_a, double* out_a, const double* part_b = nullptr, double* out_b = nullptr,
+                     Scal* test = nullptr) {
+    hipLaunchKernelGGL(kb_reduce, dim3(part_b ? 2 * NV : NV), dim3(TPB), 0, c->stream, c->batch.Pb, NV, part_a, out_a, part_b, out_b, test);
   }
 
   // z = B r for every column: the V(1,1) cycle of hf_solver.hpp's vcycle() on interleaved vectors
@@ -583,6 +588,9 @@ struct BatchOps {
       reduce(c, B.part_pAp, B.red->pAp);
       hipLaunchKernelGGL((kb_update<NV, true, DPC>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, B.red, parity, B.scal,
                          B.part_rz, B.part_zz, B.u, B.r, B.p, B.Ap, Dinv(c), c->amg[0].omega, B.z);
+      // (D^-1 r)^2 of the new iterates: columns that have converged are marked done here, so that the V-cycle below
+      // does no work for them (it used to be found out by the next iteration head, one cycle too late)
+      reduce(c, B.part_zz, B.red->zz, nullptr, nullptr, B.scal);
       vcycle(c, parity ^ 1);
     } else {
       spmv<9>(c, Avals(c), B.z, B.Ap, B.part_pAp, nullptr, B.p, B.part_rz, B.part_zz, 0.0, parity);

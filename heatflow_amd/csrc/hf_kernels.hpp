@@ -615,6 +615,19 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
       beta = rz_new / rz_old;
     }
   }
+  if (MODE == 3 && part2 != nullptr) {
+    // first kernel of a V-cycle inside the PCG loop: the update that precedes it left the (D^-1 r)^2 partials of the new
+    // iterate - if that iterate has converged, the cycle (and every later launch of this burst) is skipped here
+    // instead of after the cycle, by the next iteration head
+    double v2 = 0.0;
+    for (int k = threadIdx.x; k < npart; k += TS) v2 += part2[k];
+    const double zz = block_sum<TS / 64>(v2, s4);
+    const bool conv = zz <= scal->tol2;
+    if (conv) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) { scal->zz = zz; scal->done = 1; }
+      return;
+    }
+  }
   const ChunkIter sched(nchunks);
   for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
     const int r0 = chunk * rpc;

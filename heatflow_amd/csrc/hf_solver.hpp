@@ -235,14 +235,15 @@ void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
 // d_z2 holds z and part_rz[out_slot] the partials of r.z.  The finest level runs its two sweeps explicitly
 // (its operator changes with every re-assembly); every intermediate level is two launches, the fused
 // down leg Rt and the fused up leg GP (amg_host.hpp), the coarsest level a dense mat-vec.
-void vcycle(hf_ctx* c, int out_slot) {
+void vcycle(hf_ctx* c, int out_slot, bool test_convergence = false) {
   const int nl = static_cast<int>(c->amg.size());
   DevLevel& L0 = c->amg[0];
   if (nl == 1) {  // no coarse level: one more Jacobi sweep keeps the operator symmetric
     launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
     return;
   }
-  launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r);                 // t = r - A z
+  launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r, nullptr, nullptr,   // t = r - A z (+ early exit on convergence)
+                 test_convergence ? c->d_part_zz : nullptr);
   launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);                                // b_1 = R_0 t
   for (int l = 1; l + 1 < nl; ++l) launch_vec<0>(c, c->amg[l].Rt, c->amg[l].b, c->amg[l + 1].b);   // b_{l+1} = Rt_l b_l
   {
@@ -273,7 +274,7 @@ void launch_amg_iteration(hf_ctx* c, double* x, int parity) {
   hipLaunchKernelGGL(k_pcg_update_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
                      c->d_part_pAp, c->d_part_rz, c->d_part_zz, x, c->d_r, c->d_p, c->d_Ap, c->d_dinv,
                      c->amg[0].omega, c->d_z);
-  vcycle(c, parity ^ 1);
+  vcycle(c, parity ^ 1, true);
 }
 
 int read_scal(hf_ctx* ctx) {
