@@ -634,8 +634,12 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
     const int r1 = min(n, r0 + rpc);
     const int k0 = rowptr[r0];
     const int k1 = rowptr[r1];
-    // row-wise epilogue operands are requested before the product stream so their latency hides under it
-    const int prow = r0 + threadIdx.x;
+    // row-wise epilogue operands are requested before the product stream so their latency hides under it.
+    // Chunks of fewer rows than threads (transfer operators with long rows, MODE 0 / 6 only): tpr = TS / rpc lanes
+    // share a row's sum, so the row-sum phase uses every lane
+    const int tpr = (MODE == 0 || MODE == 6) ? TS / rpc : 1;
+    const int prow = r0 + static_cast<int>(threadIdx.x) / tpr;
+    const int psub = static_cast<int>(threadIdx.x) % tpr;
     const bool pin = prow < r1;
     int pa = 0, pb = 0;
     double e_b = 0.0, e_d = 0.0, e_y = 0.0, e_p = 0.0, e_x = 0.0;
@@ -699,7 +703,14 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
       }
     }
     __syncthreads();
-    if (pin) {
+    if ((MODE == 0 || MODE == 6) && tpr > 1) {
+      // tpr is a power of two <= 16 (rpc >= 32): the lanes of a row are neighbours inside one wavefront
+      double s = 0.0;
+      if (pin)
+        for (int j = pa + psub; j < pb; j += tpr) s += sprod[j];
+      for (int o = tpr >> 1; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+      if (pin && psub == 0) y[prow] = (MODE == 6) ? e_y + s : s;
+    } else if (pin) {
       const int row = prow;
       double s = 0.0;
       for (int j = pa; j < pb; ++j) s += sprod[j];

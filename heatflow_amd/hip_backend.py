@@ -160,6 +160,7 @@ class HeatflowHIP:
             raise HipUnavailable(f"hf_create(device {device_id}) failed ({rc}): {msg}")
         self.n = self.n_e = self.n_bc = 0
         self.nnz = 0
+        self.batch_nv = 0
 
     # -- lifetime ------------------------------------------------------------------------
     def close(self):
@@ -321,6 +322,7 @@ class HeatflowHIP:
     # -- batched time loop: nv sweep points as the columns of one multi-vector PCG ------------------
     def batch_begin(self, nv, per_column_operator=False):
         """``per_column_operator``: BATCH_SHARED (False), BATCH_PER_COLUMN (True) or BATCH_AFFINE."""
+        self.batch_nv = 0
         self._check(self._lib.hf_batch_begin(self._ctx, int(nv), int(per_column_operator)))
         self.batch_nv = int(nv)
 
@@ -349,9 +351,9 @@ class HeatflowHIP:
     def batch_run(self, g_all, rtol=1e-10, atol=0.0, max_it=20000, nodes=None):
         """g_all: (n_steps, n_bc, nv).  Returns samples (n_steps, nv, n_s) and iters (n_steps, nv)."""
         g = _f64(g_all)
-        nv = self.batch_nv
-        if g.ndim != 3 or g.shape[1] != self.n_bc or g.shape[2] != nv:
-            raise ValueError(f"batch_run: g_all must be (n_steps, {self.n_bc}, {nv})")
+        if g.ndim != 3 or g.shape[1] != self.n_bc or (self.batch_nv and g.shape[2] != self.batch_nv):
+            raise ValueError(f"batch_run: g_all must be (n_steps, {self.n_bc}, {self.batch_nv or 'nv'})")
+        nv = self.batch_nv or g.shape[2]        # no batch open on this side: the library reports it
         nsteps = g.shape[0]
         idx = _i32(nodes) if nodes is not None and len(nodes) else None
         ns = 0 if idx is None else len(idx)

@@ -430,8 +430,10 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
             cw["timing"]["num_steps"] = int(warmup_steps)
             cw["timing"]["t_final"] = dt0 * int(warmup_steps)          # same dt: the resident problem is reused
             cw["mats"]["p_sample"]["k"] = float(list(k_values)[0])
-            for sess in sessions:
-                sess.run(cw, build_stack(cw), get_watcher_points(cw))
+            from .driver import suppress_output
+            with suppress_output(True):
+                for sess in sessions:
+                    sess.run(cw, build_stack(cw), get_watcher_points(cw))
             if timing is not None:
                 timing["warmup_s"] = time.perf_counter() - t_phase
         if on_ready is not None:

@@ -1059,3 +1059,70 @@ def test_batched_time_loop_with_a_shared_operator_matches_single_runs(hip, preco
         be.run(g_cols[1][:3], prob.rtol, 0.0, prob.max_it, None)
     finally:
         prob.close()
+
+
+def test_batch_call_order_and_argument_errors(hip, case_with_diamond_small):
+    """hf_batch_*: wrong order / bad arguments are refused with a message, the context stays usable, and a batch is
+    closed by anything that invalidates what it was sized for."""
+    cfg, stack, mesh = case_with_diamond_small
+    tk, trc = material_tables(stack, mesh)
+    tags = sorted(tk)
+    with hip.HeatflowHIP(0) as be:
+        be.set_mesh(mesh.coords, mesh.tris, mesh.tags)
+        be.set_materials(tags, [tk[t] for t in tags], [trc[t] for t in tags])
+        with pytest.raises(hip.HipError, match="before hf_assemble"):
+            be.batch_begin(4)
+    prob = make_problem(cfg, stack, mesh, precond=1)              # hierarchy not frozen (amg_reuse = False)
+    be = prob.backend
+    try:
+        with pytest.raises(ValueError, match="2, 4 or 8"):
+            be.batch_begin(3)
+        with pytest.raises(ValueError, match="unknown operator kind"):
+            be.batch_begin(4, per_column_operator=5)
+        with pytest.raises(hip.HipError, match="frozen hierarchy"):
+            be.batch_begin(4, per_column_operator=hip.BATCH_PER_COLUMN)
+        with pytest.raises(hip.HipError, match="no batch is open"):
+            be.batch_run(np.zeros((1, be.n_bc, 4)))
+        be.batch_begin(4)                                           # shared operator: fine without a frozen hierarchy
+        with pytest.raises(hip.HipError, match="per-column"):
+            be.batch_load_column(0)
+        with pytest.raises(hip.HipError, match="affine"):
+            be.batch_set_affine([mesh.material_tags["p_sample"]], [0.0, 0.1, 0.2, 0.3])
+        with pytest.raises(ValueError, match="column"):
+            be.batch_set_state(4, np.zeros(prob.n))
+        with pytest.raises(ValueError):
+            be.batch_run(np.zeros((2, be.n_bc + 1, 4)))             # wrong boundary-value shape (checked by the binding)
+        be.set_precond(1, True)                                     # same kind: the batch survives ...
+        be.batch_set_state(0, np.full(prob.n, 300.0))
+        be.set_dirichlet(prob.bc_dofs)                              # ... a new Dirichlet set closes it
+        with pytest.raises(hip.HipError, match="no batch is open"):
+            be.batch_set_state(0, np.full(prob.n, 300.0))
+        be.assemble(prob.dt, prob.assembly_mode)
+        be.batch_begin(2, per_column_operator=hip.BATCH_AFFINE)
+        with pytest.raises(hip.HipError, match="hf_batch_set_affine has not been called"):
+            be.batch_run(np.zeros((1, be.n_bc, 2)))
+        with pytest.raises(ValueError, match="not a cell tag"):
+            be.batch_set_affine([999], [0.0, 0.1])
+        be.batch_end()
+        prob.set_state(300.0)                                       # and the context steps on its own again
+        for bc in prob.bcs:
+            bc.update(0.0)
+        prob.step(prob.dt)
+    finally:
+        prob.close()
+
+
+@pytest.mark.parametrize("precond", [0, 1])
+def test_time_loop_is_bitwise_reproducible(hip, precond, case_with_diamond_small):
+    """Fixed-order reductions everywhere (partial sums, projection start vector, row-gather assembly): two runs of
+    the same problem give the same bits and the same iteration counts."""
+    cfg, stack, mesh = case_with_diamond_small
+    out = []
+    for _ in range(2):
+        prob = make_problem(cfg, stack, mesh, precond=precond)
+        try:
+            _, _, iters = prob.run(25, time_varying=[prob.bcs[3]])
+            out.append((prob.state(), iters.copy()))
+        finally:
+            prob.close()
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
