@@ -269,6 +269,11 @@ def run_sweep64(ranks, n_points, steps_per_point, warmup_steps, concurrent, batc
                      f"{concurrent} loops in flight per rank, steps 0..{steps_per_point - 1} per point"),
         "points": n_points, "n_dof": n_dof, "steps_per_point": steps_per_point, "concurrent_per_rank": concurrent,
         "batch": batch, "rank0_batches": timing.get("batches"),
+        "iteration_head_bytes_per_dof_update": {
+            "what": ("algorithmic bytes of the PCG iteration head per row and column at nnz = 7 n: one run per point "
+                     "12*nnz + 44*n; batched with the affine operator family (two shared value arrays, shared indices) "
+                     "(4 + 16)*nnz/nv + 44*n"),
+            "one_run_per_point": 12 * 7 + 44, "batched": (4 + 16) * 7 / max(batch, 1) + 44 if batch > 1 else 12 * 7 + 44},
         "wall_s": wall, "value": n_points * n_dof * steps_per_point / wall, "unit": "DOF-updates/s",
         "points_per_s": n_points / wall, "pcg_iters_per_step_mean": float(np.mean([r["pcg_iters_mean"] for r in rows])),
         "rank0_phases_s": {k: timing.get(k) for k in ("mesh_s", "broadcast_s", "warmup_s", "points_s")},
