@@ -492,6 +492,8 @@ def main(argv=None):
     p.add_argument("--mesh-folder", default="meshes")
     p.add_argument("--write-xdmf", action="store_true")
     p.add_argument("--verbose", action="store_true")
+    p.add_argument("--batch", type=int, default=8,
+                   help="points of a rank advanced together by the batched time loop (8, 4, 2; 1 = one run per point)")
     a = p.parse_args(argv)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch
@@ -501,7 +503,7 @@ def main(argv=None):
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl" if use_gpu else "gloo")
     run_parameter_sweep(a.config, a.output_dir, tuple(a.fwhm_range), tuple(a.k_range), tuple(a.width_range),
-                        tuple(a.num_points), a.mesh_folder, a.write_xdmf, not a.verbose)
+                        tuple(a.num_points), a.mesh_folder, a.write_xdmf, not a.verbose, batch=a.batch)
     d = _dist()
     if d is not None:
         d.destroy_process_group()

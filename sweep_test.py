@@ -24,7 +24,7 @@ def main():
     cfg["heating"]["file"] = os.path.join(here, cfg["heating"]["file"])
     t0 = time.time()
     rows = ps.run_kappa_sweep(cfg, "meshes/test1", ps.get_k_values(), "outputs/sweep_test", rebuild_mesh=True,
-                              exp_csv=cfg["heating"]["file"], concurrent=4)   # 4 points in flight per GPU
+                              exp_csv=cfg["heating"]["file"], batch=8, concurrent=2)   # batches of 8 points, 2 time loops in flight per GPU
     if ps.world_info()[0] == 0:
         ok = [r for r in rows if r["status"] == "success"]
         best = min(ok, key=lambda r: r["rmse"])
