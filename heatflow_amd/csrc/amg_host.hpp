@@ -245,6 +245,9 @@ struct Params {
   // (the damped-Jacobi sweep, and with it the V-cycle, stays SPD).  Measured at 1M DOF: 1.0 -> 16, 1.2 -> 14,
   // 1.4 -> 13.5 PCG iterations per step.  The prolongator keeps the classical 4/(3 rho).
   double smooth_scale = 1.4;
+  // Also fold the FINEST level's two smoothing sweeps into the transfer operators (Rt, GP as on the intermediate
+  // levels): the preconditioner then never passes over the fine operator itself, only over (I - w D^-1 A) P and G.
+  bool fuse_fine = false;
 };
 
 // Build from the fine operator A0 (moved in; released after the first Galerkin product).
@@ -275,7 +278,7 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
       L.R = transpose(L.P);
       Csr AP = spgemm(A, L.P);
       Csr Ac = spgemm(L.R, AP);
-      if (lev > 0) {                                 // intermediate level: fused legs of the cycle
+      if (lev > 0 || prm.fuse_fine) {                // fused legs of the cycle (intermediate levels; the finest on request)
         const Csr Pt = smoothed_by_product(L.P, AP, L.dinv, L.omega);
         L.Rt = transpose(Pt);
         L.GP = fused_up_leg(A, L.dinv, L.omega, Pt);

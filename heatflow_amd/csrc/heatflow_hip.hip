@@ -118,7 +118,8 @@ int install_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int
   ctx->have_prev = false;
   free_responses(ctx);
   HF_TRY(dev_alloc(ctx, &ctx->d_b, n));
-  HF_TRY(dev_alloc(ctx, &ctx->d_r, n));
+  HF_TRY(dev_alloc(ctx, &ctx->d_r, 2 * static_cast<size_t>(n) + 4));   // the level-1 result of a fused finest level lives behind r: [r; x_1]
+  HF_HIP(hipMemsetAsync(ctx->d_r, 0, sizeof(double) * (2 * static_cast<size_t>(n) + 4), ctx->stream));
   HF_TRY(dev_alloc(ctx, &ctx->d_p, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_Ap, n));
   HF_TRY(dev_alloc(ctx, &ctx->d_tmp, n));

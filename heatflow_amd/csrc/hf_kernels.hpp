@@ -562,6 +562,7 @@ __global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* 
 //   MODE 4: y = x + w D^-1 (b - A x), partials b.y                   (damped-Jacobi sweep, fused r.z)
 //   MODE 5: y = b - A x; p = w D^-1 y; partials (D^-1 y)^2, (D^-1 b)^2   (AMG-PCG start)
 //   MODE 6: y += A x                                                 (multigrid prolongation)
+//   MODE 7: y = A x, partials b.y                                    (fused up leg of the finest level: z = GP [r; e], r.z)
 //   MODE 8: y = A x; p = 2 x - b        (RHS b = M u^n fused with the extrapolated start
 //           2 u^n - u^{n-1} of the next solve; `b` carries u^{n-1})
 //   MODE 9: PCG iteration head (x = z): convergence test, beta, Ap <- A z + beta Ap, p <- z + beta p,
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
       beta = rz_new / rz_old;
     }
   }
-  if (MODE == 3 && part2 != nullptr) {
+  if ((MODE == 3 || MODE == 0) && part2 != nullptr) {
     // first kernel of a V-cycle inside the PCG loop: the update that precedes it left the (D^-1 r)^2 partials of the new
     // iterate - if that iterate has converged, the cycle (and every later launch of this burst) is skipped here
     // instead of after the cycle, by the next iteration head
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
     // row-wise epilogue operands are requested before the product stream so their latency hides under it.
     // Chunks of fewer rows than threads (transfer operators with long rows, MODE 0 / 6 only): tpr = TS / rpc lanes
     // share a row's sum, so the row-sum phase uses every lane
-    const int tpr = (MODE == 0 || MODE == 6) ? TS / rpc : 1;
+    const int tpr = (MODE == 0 || MODE == 6 || MODE == 7) ? TS / rpc : 1;
     const int prow = r0 + static_cast<int>(threadIdx.x) / tpr;
     const int psub = static_cast<int>(threadIdx.x) % tpr;
     const bool pin = prow < r1;
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
     if (pin) {
       pa = rowptr[prow] - k0;
       pb = rowptr[prow + 1] - k0;
-      if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 8) e_b = bvec[prow];
+      if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8) e_b = bvec[prow];
       if (MODE == 2 || MODE == 4 || MODE == 5) e_d = dinv[prow];
       if (MODE == 6 || (MODE == 9 && !first9)) e_y = y[prow];
       if (MODE == 9 && !first9) e_p = pvec[prow];
@@ -703,13 +704,16 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
       }
     }
     __syncthreads();
-    if ((MODE == 0 || MODE == 6) && tpr > 1) {
+    if ((MODE == 0 || MODE == 6 || MODE == 7) && tpr > 1) {
       // tpr is a power of two <= 16 (rpc >= 32): the lanes of a row are neighbours inside one wavefront
       double s = 0.0;
       if (pin)
         for (int j = pa + psub; j < pb; j += tpr) s += sprod[j];
       for (int o = tpr >> 1; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-      if (pin && psub == 0) y[prow] = (MODE == 6) ? e_y + s : s;
+      if (pin && psub == 0) {
+        y[prow] = (MODE == 6) ? e_y + s : s;
+        if (MODE == 7) acc0 += e_b * s;
+      }
     } else if (pin) {
       const int row = prow;
       double s = 0.0;
@@ -736,6 +740,9 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
         pvec[row] = w * e_d * ri;
         acc1 += (e_d * ri) * (e_d * ri);
         acc2 += (e_d * e_b) * (e_d * e_b);
+      } else if (MODE == 7) {
+        y[row] = s;
+        acc0 += e_b * s;
       } else if (MODE == 6) {
         y[row] = e_y + s;
       } else if (MODE == 8) {
@@ -752,7 +759,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
     __syncthreads();
   }
   // consumers sum `npart` slots in a fixed order; this launch has fewer workgroups, the rest are zeros
-  if (MODE == 2 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {
+  if (MODE == 2 || MODE == 7 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {
     const double t0 = block_sum<TS / 64>(acc0, s4);
     if (threadIdx.x == 0) {
       part0[blockIdx.x] = t0;
@@ -1213,7 +1220,7 @@ __global__ __launch_bounds__(TPB) void k_pcg_update_amg(int n, int nchunks, int 
       const double zi = dinv[i] * ri;
       x[i] += alpha * p[i];
       r[i] = ri;
-      z0[i] = w * zi;
+      if (z0 != nullptr) z0[i] = w * zi;      // not needed when the finest level runs through its fused legs
       a_zz += zi * zi;
     }
   }

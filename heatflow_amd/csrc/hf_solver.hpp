@@ -91,6 +91,12 @@ int build_amg(hf_ctx* ctx) {
   if (const char* e = std::getenv("HEATFLOW_AMG_THETA")) prm.theta = std::atof(e);          // tuning knobs
   if (const char* e = std::getenv("HEATFLOW_AMG_COARSE")) prm.coarse_size = std::atoi(e);
   if (const char* e = std::getenv("HEATFLOW_AMG_SMOOTH_SCALE")) prm.smooth_scale = std::atof(e);
+  // Finest level through fused legs when the fine operator no longer fits the 256 MiB Infinity Cache: the explicit
+  // sweeps read A three times per iteration, which is nearly free while A stays cache-resident (1M DOF: fused +2 %)
+  // and the dominant HBM traffic once it does not (4M DOF: -9 %, 16M DOF: -8 % per iteration, same iteration counts)
+  ctx->amg_fuse0 = static_cast<size_t>(ctx->nnz) * 12 > (static_cast<size_t>(256) << 20);
+  if (const char* e = std::getenv("HEATFLOW_AMG_FUSE0")) ctx->amg_fuse0 = (e[0] != '0');
+  prm.fuse_fine = ctx->amg_fuse0;
   if (!amg::build(std::move(A0), prm, H)) return fail(ctx, HF_ERR_STATE, "AMG set-up failed (non-positive diagonal or singular coarse operator)");
   const size_t nl = H.levels.size();
   ctx->amg.resize(nl);
@@ -102,6 +108,14 @@ int build_amg(hf_ctx* ctx) {
     if (l == 0) {
       L.A.nrow = L.A.ncol = ctx->n; L.A.nnz = ctx->nnz; L.A.ptr = ctx->d_rowptr; L.A.idx = ctx->d_colidx; L.A.val = ctx->d_A;
       L.dinv = ctx->d_dinv;
+      if (nl > 1 && hl.Rt.nrow > 0) {            // fused finest level: GP's operand is [r; x_1] = d_r with the level-1 result behind it
+        HF_TRY(upload_csr(ctx, hl.Rt, L.Rt, f32));
+        HF_TRY(upload_csr(ctx, hl.GP, L.GP, f32));
+        if (L.Rt.rpc == 0 || L.GP.rpc == 0) {    // too small for the LDS-staged kernel (the only one with the r.z epilogue): explicit sweeps
+          free_dev_csr(L.Rt);
+          free_dev_csr(L.GP);
+        }
+      }
     } else {
       HF_TRY(upload_csr(ctx, hl.A, L.A));
       HF_TRY(dev_alloc(ctx, &L.dinv, L.n));
@@ -120,7 +134,7 @@ int build_amg(hf_ctx* ctx) {
       }
       if (l == 1) {
         HF_TRY(dev_alloc(ctx, &L.x, L.n + 2));
-        L.res = L.x;
+        L.res = ctx->amg[0].GP.nrow > 0 ? ctx->d_r + ctx->n : L.x;
       } else {
         L.res = ctx->amg[l - 1].cat + ctx->amg[l - 1].n;
       }
@@ -186,6 +200,31 @@ int build_amg(hf_ctx* ctx) {
 
 // VMODE 0: y = A x, 1: y += A x; LDS-staged kernel when the matrix is big enough to fill the chip,
 // sub-wave kernel otherwise.
+// LDS-staged kernel on an operator of the hierarchy in mode SM (0: y = A x, 7: y = A x with b.y partials), optional
+// early exit on the convergence partials `conv_part`.  The operator must be one the stream kernel runs (rpc > 0).
+template <int SM, typename VT>
+void launch_stream_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y, double* part0, const double* bvec,
+                     double* conv_part) {
+  const int npart = c->P;                  // the consumers of part0 sum c->P slots: never more workgroups than that
+  int grid = std::min(m.nchunks, npart);
+  if (grid >= 64) grid &= ~7;
+#define HF_STREAM_ARGS2 m.nrow, m.nchunks, m.rpc, m.ptr, m.idx, val, x, y, c->d_scal, part0, bvec, static_cast<const double*>(nullptr), \
+                        static_cast<double*>(nullptr), static_cast<double*>(nullptr), conv_part, 0.0, npart, 0
+  if (m.cid != nullptr)
+    hipLaunchKernelGGL((k_spmv<SM, true, VT>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz + m.max_dict) * 8, c->stream,
+                       HF_STREAM_ARGS2, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz});
+  else
+    hipLaunchKernelGGL((k_spmv<SM, false, VT>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream,
+                       HF_STREAM_ARGS2, ColComp{nullptr, nullptr, nullptr, 0});
+#undef HF_STREAM_ARGS2
+}
+
+template <int SM>
+void launch_stream(hf_ctx* c, const DevCsr& m, const double* x, double* y, double* part0, const double* bvec, double* conv_part) {
+  if (m.valf != nullptr) launch_stream_t<SM, float>(c, m, m.valf, x, y, part0, bvec, conv_part);
+  else launch_stream_t<SM, double>(c, m, m.val, x, y, part0, bvec, conv_part);
+}
+
 template <int VMODE, typename VT>
 void launch_vec_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y) {
   if (m.rpc > 0) {
@@ -242,9 +281,16 @@ void vcycle(hf_ctx* c, int out_slot, bool test_convergence = false) {
     launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
     return;
   }
-  launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r, nullptr, nullptr,   // t = r - A z (+ early exit on convergence)
-                 test_convergence ? c->d_part_zz : nullptr);
-  launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);                                // b_1 = R_0 t
+  const bool fused0 = L0.GP.nrow > 0;
+  if (fused0) {
+    // finest level through its fused legs: b_1 = Rt_0 r (pre-smoothing from zero, residual and restriction in one
+    // operator; early exit if the update before it has converged)
+    launch_stream<0>(c, L0.Rt, c->d_r, c->amg[1].b, nullptr, nullptr, test_convergence ? c->d_part_zz : nullptr);
+  } else {
+    launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r, nullptr, nullptr,   // t = r - A z (+ early exit on convergence)
+                   test_convergence ? c->d_part_zz : nullptr);
+    launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);                              // b_1 = R_0 t
+  }
   for (int l = 1; l + 1 < nl; ++l) launch_vec<0>(c, c->amg[l].Rt, c->amg[l].b, c->amg[l + 1].b);   // b_{l+1} = Rt_l b_l
   {
     DevLevel& Lc = c->amg[nl - 1];
@@ -260,6 +306,11 @@ void vcycle(hf_ctx* c, int out_slot, bool test_convergence = false) {
     }
   }
   for (int l = nl - 2; l >= 1; --l) launch_vec<0>(c, c->amg[l].GP, c->amg[l].cat, c->amg[l].res);  // x_l = GP_l [b_l; x_{l+1}]
+  if (fused0) {
+    // z = GP_0 [r; x_1] (prolongation and post-smoothing in one operator) with the r.z partials
+    launch_stream<7>(c, L0.GP, c->d_r, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr);
+    return;
+  }
   launch_vec<1>(c, L0.P, c->amg[1].res, c->d_z);                                // z += P_0 x_1
   launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
 }
@@ -273,7 +324,7 @@ void launch_amg_iteration(hf_ctx* c, double* x, int parity) {
   if (timed) c->prof_used++;
   hipLaunchKernelGGL(k_pcg_update_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
                      c->d_part_pAp, c->d_part_rz, c->d_part_zz, x, c->d_r, c->d_p, c->d_Ap, c->d_dinv,
-                     c->amg[0].omega, c->d_z);
+                     c->amg[0].omega, c->amg[0].GP.nrow > 0 ? static_cast<double*>(nullptr) : c->d_z);
   vcycle(c, parity ^ 1, true);
 }
 
