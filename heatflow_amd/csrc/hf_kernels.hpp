@@ -588,7 +588,10 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
                                               int parity, ColComp comp) {
   extern __shared__ double sprod[];
   __shared__ double s4[TS / 64];
+  // launches inside the PCG loop return at once after convergence; MODE 0 / 7 are also used outside it (right-hand
+  // side, debug products), where the launcher passes no `scal`
   if ((MODE == 3 || MODE == 4 || MODE == 6 || MODE == 9) && scal->done) return;
+  if ((MODE == 0 || MODE == 7) && scal != nullptr && scal->done) return;
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   double beta = 0.0;
   bool first9 = false;
@@ -1061,6 +1064,15 @@ __global__ __launch_bounds__(TPB) void k_proj_combine(int n, ProjVecs a, const d
     for (int k = 0; k < PROJ_MT; ++k)
       if (k < a.m) s += c[k] * a.V[k][i];
     u[i] = s;
+  }
+}
+
+// two vector copies in one launch (projection ring: solution and right-hand side)
+__global__ __launch_bounds__(TPB) void k_copy2(int n, const double* __restrict__ a, double* __restrict__ a_out,
+                                               const double* __restrict__ b, double* __restrict__ b_out) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+    a_out[i] = a[i];
+    b_out[i] = b[i];
   }
 }
 

@@ -357,7 +357,6 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
                        ctx->d_part_bn, ctx->d_scal);
   } else {
     // r = b - A x, z0 = w D^-1 r; tolerance; z = B r (V-cycle, r.z into slot 0)
-    HF_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(Scal), ctx->stream));   // done = 0 so the start kernels run
     launch_spmv<5>(ctx, sys.A, sys.x, ctx->d_r, nullptr, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn,
                    ctx->amg[0].omega);
     hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
@@ -448,8 +447,8 @@ ProjVecs proj_active(const hf_ctx* ctx) {
 // store (u with zeroed Dirichlet entries, right-hand side) in `slot`; its Gram column is computed by the next proj_column
 int proj_store(hf_ctx* ctx, int slot, const double* u, const double* rhs) {
   hf_ctx::Proj& Q = ctx->proj;
-  HF_HIP(hipMemcpyAsync(Q.V[slot], u, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
-  HF_HIP(hipMemcpyAsync(Q.F[slot], rhs, sizeof(double) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+  // one kernel for both copies: a device-to-device hipMemcpyAsync costs several times a launch on the host side
+  hipLaunchKernelGGL(k_copy2, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, u, Q.V[slot], rhs, Q.F[slot]);
   if (ctx->nbc > 0)
     hipLaunchKernelGGL(k_zero_entries, dim3((ctx->nbc + 255) / 256), dim3(256), 0, ctx->stream, ctx->nbc, ctx->d_bc_dofs, Q.V[slot]);
   Q.used[slot] = true;
@@ -546,9 +545,8 @@ int step_device(hf_ctx* ctx, const double* g_host, const double* g_dev, double r
   if (projected) HF_TRY(proj_ensure(ctx));
   const bool hist_ok = nb > 0 && ctx->extrapolate && ctx->have_prev && ctx->g_hist >= 2;
   if (ctx->start_kind >= 2 && hist_ok) HF_TRY(prepare_response(ctx, g_host, max_it, &ra));
-  if (nb > 0)
-    HF_HIP(hipMemcpyAsync(ctx->d_g, g_dev ? g_dev : g_host, sizeof(double) * nb,
-                          g_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  const double* g = g_dev ? g_dev : ctx->d_g;   // hf_run has every step's boundary values on the device already
+  if (nb > 0 && !g_dev) HF_HIP(hipMemcpyAsync(ctx->d_g, g_host, sizeof(double) * nb, hipMemcpyHostToDevice, ctx->stream));
   if (projected) {
     // b = M u^n, lifting, set_bc; then the start vector = A-norm projection of the new solution on the span of the last
     // solutions and the boundary responses (kind 3)
@@ -574,9 +572,9 @@ int step_device(hf_ctx* ctx, const double* g_host, const double* g_dev, double r
   if (nb > 0) {
     if (ctx->nlift_rows > 0)  // apply_lifting (:477)
       hipLaunchKernelGGL(k_lift, dim3((ctx->nlift_rows + 255) / 256), dim3(256), 0, ctx->stream, ctx->nlift_rows,
-                         ctx->d_lift_rows, ctx->d_lift_ptr, ctx->d_lift_bc, ctx->d_lift_val, ctx->d_g, ctx->d_b);
+                         ctx->d_lift_rows, ctx->d_lift_ptr, ctx->d_lift_bc, ctx->d_lift_val, g, ctx->d_b);
     // set_bc (:479); the same values seed the iterate
-    hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, ctx->d_g,
+    hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, g,
                        ctx->d_b, ctx->d_u);
   }
   if (projected && proj_active(ctx).m > 0) {
@@ -585,7 +583,7 @@ int step_device(hf_ctx* ctx, const double* g_host, const double* g_dev, double r
     Q.pending = -1;
     hipLaunchKernelGGL(k_proj_combine, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, proj_active(ctx), Q.alpha, ctx->d_u);
     if (nb > 0)
-      hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, ctx->d_g, ctx->d_b, ctx->d_u);
+      hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, g, ctx->d_b, ctx->d_u);
   }
   const LinSys sys{ctx->d_A, ctx->d_dinv, ctx->d_u, ctx->d_b};
   const bool use_amg = ctx->precond == 1 && ctx->amg_ready;
