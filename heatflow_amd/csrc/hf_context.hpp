@@ -37,6 +37,16 @@ constexpr int MAXRESP = 4;     // boundary-response directions kept per operator
 constexpr int TS = 512;        // SpMV workgroup: 512 threads = 8 wavefronts own 512 consecutive rows per chunk
                                // (4 such workgroups per CU = 32 waves/CU; measured 20 % faster than 256x16)
 
+// Host-visible progress of the running solve (pinned, mapped memory): written by the one thread that changes the
+// device-resident scalars, so the host follows the convergence tests by reading its own memory - no copy, no
+// synchronisation - and queues the next iteration while the current V-cycle is still running.
+struct ScalMirror {
+  double zz, bn2;
+  int iters;                   // updates done when the last test ran
+  int done;                    // as Scal::done
+  int tested;                  // -1 until the start kernel has run, then the iteration count whose iterate was tested last
+};
+
 struct Scal {                  // device-resident PCG scalars
   double tol2;                 // (max(rtol*||D^-1 b||, atol))^2
   double bn2;                  // ||D^-1 b||^2
@@ -44,6 +54,7 @@ struct Scal {                  // device-resident PCG scalars
   int iters;
   int done;                    // 0 running, 1 converged, 2 breakdown
   int first;                   // 1 until the first update of a solve: the first direction is p = z (beta = 0)
+  ScalMirror* mirror;          // device address of the host mirror, or null (batched columns)
 };
 
 // Per-column scalars of the batched PCG (hf_batch.hpp), each reduced once per producer by a one-workgroup kernel
@@ -136,6 +147,8 @@ struct hf_ctx {
   double *d_part_pAp = nullptr, *d_part_rz = nullptr, *d_part_zz = nullptr, *d_part_bn = nullptr;
   Scal* d_scal = nullptr;
   Scal* h_scal = nullptr;      // pinned
+  ScalMirror* h_mirror = nullptr;   // pinned + mapped; d_mirror is its device address
+  ScalMirror* d_mirror = nullptr;
   int32_t* d_samp_idx = nullptr;
   double* d_samp = nullptr;
   int samp_cap = 0;

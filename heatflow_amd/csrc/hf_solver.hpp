@@ -328,9 +328,53 @@ void launch_amg_iteration(hf_ctx* c, double* x, int parity) {
   vcycle(c, parity ^ 1, true);
 }
 
+// device scalars = zero, with the address of the host mirror (complete on return)
+int reset_scal(hf_ctx* ctx) {
+  *ctx->h_scal = Scal{};
+  ctx->h_scal->mirror = ctx->d_mirror;
+  HF_HIP(hipMemcpyAsync(ctx->d_scal, ctx->h_scal, sizeof(Scal), hipMemcpyHostToDevice, ctx->stream));
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  return HF_OK;
+}
+
+void harvest_profile(hf_ctx* ctx);
+
 int read_scal(hf_ctx* ctx) {
   HF_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
   HF_HIP(hipStreamSynchronize(ctx->stream));
+  harvest_profile(ctx);
+  return HF_OK;
+}
+
+// Wait - reading host memory only - until the iterate after update `k` has been tested (k = 0: the start kernel has run)
+// or the solve has ended; h_scal receives what the mirror holds.  A device that makes no progress for
+// HEATFLOW_POLL_TIMEOUT_S seconds (default 60) is an error, not a hang of the caller.
+int wait_tested(hf_ctx* ctx, int k) {
+  static const double limit_s = std::getenv("HEATFLOW_POLL_TIMEOUT_S") ? std::atof(std::getenv("HEATFLOW_POLL_TIMEOUT_S")) : 60.0;
+  ScalMirror* m = ctx->h_mirror;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 1;; ++spin) {
+    const int tested = __atomic_load_n(&m->tested, __ATOMIC_ACQUIRE);
+    const int done = __atomic_load_n(&m->done, __ATOMIC_ACQUIRE);
+    if (tested >= k || done != 0) break;
+    if ((spin & 0xfff) == 0) {
+      if (hipStreamQuery(ctx->stream) == hipSuccess) {     // everything queued has run: the test we wait for was never launched, or a launch failed
+        if (__atomic_load_n(&m->tested, __ATOMIC_ACQUIRE) >= k || __atomic_load_n(&m->done, __ATOMIC_ACQUIRE) != 0) break;
+        return fail(ctx, HF_ERR_HIP, "PCG progress: stream drained before the test of iteration %d ran (%s)", k, hipGetErrorString(hipGetLastError()));
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+        return fail(ctx, HF_ERR_HIP, "PCG progress: no convergence test within %.0f s (waiting for iteration %d, at %d)", limit_s, k, tested);
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  ctx->h_scal->iters = m->iters;
+  ctx->h_scal->zz = m->zz;
+  ctx->h_scal->bn2 = m->bn2;
+  ctx->h_scal->done = __atomic_load_n(&m->done, __ATOMIC_ACQUIRE);
+  return HF_OK;
+}
+
+void harvest_profile(hf_ctx* ctx) {
   if (ctx->prof) {  // harvest the event pairs of this burst (only launches that really ran count)
     for (int k = 0; k < ctx->prof_used; ++k) {
       float ms = 0.f;
@@ -342,13 +386,15 @@ int read_scal(hf_ctx* ctx) {
     }
     ctx->prof_used = 0;
   }
-  return HF_OK;
 }
 
 // PCG on `sys` started from sys.x.  Jacobi: any system on the pattern; AMG: the main system only.
 // Iteration count / residual are left in h_scal; *pred carries the burst-size hint between calls.
 int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double atol, int max_it, int* pred) {
   static const bool trace_res = std::getenv("HEATFLOW_TRACE_RES") != nullptr;   // diagnostics: bursts of 2, residual printed after each
+  // the previous solve has ended (its outcome was read), nothing in flight writes the mirror: reset it for this one
+  __atomic_store_n(&ctx->h_mirror->done, 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&ctx->h_mirror->tested, -1, __ATOMIC_RELEASE);
   if (!use_amg) {
     // r = b - A x, z = D^-1 r, r.z
     launch_spmv<2>(ctx, sys.A, sys.x, ctx->d_r, ctx->d_part_rz, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn, 0.0,
@@ -366,6 +412,38 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
   HF_HIP(hipGetLastError());
 
   int launched = 0;
+  if (use_amg && !trace_res && ctx->amg.size() > 1) {   // (a one-level hierarchy has no V-cycle kernel that tests: bursts below)
+    // Multigrid iterations are queued one test ahead: the first kernel of a V-cycle publishes the convergence test of
+    // the iterate it starts from (ScalMirror), so the host learns the outcome while that cycle still has its other ten
+    // kernels to run and has the next iteration queued before they finish - no copy, no synchronisation, no idle
+    // device between bursts, and no iteration launched beyond the converged one except inside the first burst
+    // (previous count - 2: the counts drift slowly).
+    ctx->prof_base = 0;
+    auto finish = [&](int rc) {
+      if (ctx->prof) { (void)hipStreamSynchronize(ctx->stream); harvest_profile(ctx); }
+      return rc;
+    };
+    if (*pred <= 0) {  // previous solve needed no iteration (e.g. constant field): look before launching
+      HF_TRY(wait_tested(ctx, 0));
+      if (ctx->h_scal->done == 1) return finish(HF_OK);
+    }
+    int burst = std::max(1, std::min(max_it, *pred - 2));
+    while (true) {
+      for (int k = 0; k < burst; ++k) launch_amg_iteration(ctx, sys.x, (launched + k) & 1);
+      launched += burst;
+      HF_HIP(hipGetLastError());
+      const int rc = wait_tested(ctx, launched);
+      if (rc != HF_OK) return finish(rc);
+      if (ctx->h_scal->done || launched >= max_it) break;
+      burst = 1;
+    }
+    *pred = ctx->h_scal->iters;
+    if (ctx->h_scal->done == 2) return finish(fail(ctx, HF_ERR_NOCONV, "PCG breakdown (p.Ap <= 0) after %d iterations", ctx->h_scal->iters));
+    if (!ctx->h_scal->done)
+      return finish(fail(ctx, HF_ERR_NOCONV, "PCG not converged in %d iterations (rel. residual %.3e)", ctx->h_scal->iters,
+                         std::sqrt(ctx->h_scal->zz / std::max(ctx->h_scal->bn2, 1e-300))));
+    return finish(HF_OK);
+  }
   if (*pred <= 0) {  // previous solve needed no iteration (e.g. constant field): look before launching
     HF_TRY(read_scal(ctx));
     if (ctx->h_scal->done == 1) return HF_OK;
