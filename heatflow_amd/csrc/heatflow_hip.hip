@@ -838,6 +838,10 @@ int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t operator_kind) {
   HF_HIP(hipMemsetAsync(B.pG, 0, sizeof(double) * nv * PROJ_MT * PROJ_MT, ctx->stream));
   B.pnext = 0; B.ppending = -1;
   if (hipHostMalloc(reinterpret_cast<void**>(&B.h_scal), sizeof(Scal) * nv) != hipSuccess) return fail(ctx, HF_ERR_ALLOC, "hipHostMalloc failed");
+  if (hipHostMalloc(reinterpret_cast<void**>(&B.h_mirror), sizeof(ScalMirror) * nv, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&B.d_mirror), B.h_mirror, 0) != hipSuccess)
+    return fail(ctx, HF_ERR_ALLOC, "hipHostMalloc (mapped) failed");
+  for (int j = 0; j < nv; ++j) B.h_mirror[j] = ScalMirror{0.0, 0.0, 0, 0, -1};
   const int rpb = TPB / nv;
   B.Pb = static_cast<int>(std::min<size_t>((n + rpb - 1) / rpb, MAXP));
   if (B.Pb >= 64) B.Pb &= ~7;

@@ -61,7 +61,8 @@ __device__ __forceinline__ double col_partials(const double* __restrict__ part /
 // one workgroup per (array, column): 256 threads add the column's P partials in a fixed order
 __global__ __launch_bounds__(TPB) void kb_reduce(int P, int nv, const double* __restrict__ part_a, double* __restrict__ out_a,
                                                  const double* __restrict__ part_b, double* __restrict__ out_b,
-                                                 Scal* __restrict__ test /* non-null: out_a is (D^-1 r)^2 - mark converged columns done */) {
+                                                 Scal* __restrict__ test /* non-null: out_a is (D^-1 r)^2 - mark converged columns done */,
+                                                 ScalMirror* __restrict__ mirror /* with test: publish each column's outcome to the host */) {
   __shared__ double s4[4];
   const int j = blockIdx.x % nv;
   const bool second = blockIdx.x >= nv;
@@ -78,7 +79,10 @@ __global__ __launch_bounds__(TPB) void kb_reduce(int P, int nv, const double* __
   const double t = block_sum(v, s4);
   if (threadIdx.x == 0) {
     (second ? out_b : out_a)[j] = t;
-    if (test != nullptr && !second && test[j].done == 0 && t <= test[j].tol2) { test[j].zz = t; test[j].done = 1; }
+    if (test != nullptr && !second) {
+      if (test[j].done == 0 && t <= test[j].tol2) { test[j].zz = t; test[j].done = 1; }
+      if (mirror != nullptr) mirror_publish(mirror + j, t, test[j].iters, test[j].done);
+    }
   }
 }
 
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(TPB) void kb_scale(int n, double w, const double* _
 template <int NV>
 __global__ __launch_bounds__(TPB) void kb_begin(int P, double rtol, double atol, const double* __restrict__ part_zz,
                                                 const double* __restrict__ part_bn, const double* __restrict__ part_rz0,
-                                                Scal* __restrict__ scal, BRed* __restrict__ red) {
+                                                Scal* __restrict__ scal, BRed* __restrict__ red, ScalMirror* __restrict__ mirror) {
   __shared__ double sw[4 * NV];
   const int j = threadIdx.x % NV;
   const double zz = col_partials<NV>(part_zz + j * MAXP, P, sw);
@@ -292,6 +296,10 @@ __global__ __launch_bounds__(TPB) void kb_begin(int P, double rtol, double atol,
     red->zz[j] = zz;
     red->bn[j] = bn2;
     if (part_rz0 != nullptr) red->rz[0][j] = rz0;
+    if (mirror != nullptr) {
+      mirror[j].bn2 = bn2;
+      mirror_publish(mirror + j, zz, 0, sc->done);
+    }
   }
 }
 
@@ -473,6 +481,7 @@ void free_batch_state(hf_ctx::Batch& B) {
   for (auto& L : B.lev) { dev_free(&L.x); dev_free(&L.cat); if (L.own_b) dev_free(&L.b); }
   B.lev.clear();
   if (B.h_scal) { (void)hipHostFree(B.h_scal); B.h_scal = nullptr; }
+  if (B.h_mirror) { (void)hipHostFree(B.h_mirror); B.h_mirror = B.d_mirror = nullptr; }
   B.nv = 0;
   B.sysA = B.sysDinv = nullptr;
 }
@@ -543,7 +552,8 @@ struct BatchOps {
 
   static void reduce(hf_ctx* c, const double* part_a, double* out_a, const double* part_b = nullptr, double* out_b = nullptr,
                      Scal* test = nullptr) {
-    hipLaunchKernelGGL(kb_reduce, dim3(part_b ? 2 * NV : NV), dim3(TPB), 0, c->stream, c->batch.Pb, NV, part_a, out_a, part_b, out_b, test);
+    hipLaunchKernelGGL(kb_reduce, dim3(part_b ? 2 * NV : NV), dim3(TPB), 0, c->stream, c->batch.Pb, NV, part_a, out_a, part_b, out_b, test,
+                       test ? c->batch.d_mirror : static_cast<ScalMirror*>(nullptr));
   }
 
   // z = B r for every column: the V(1,1) cycle of hf_solver.hpp's vcycle() on interleaved vectors
@@ -614,22 +624,82 @@ struct BatchOps {
     return HF_OK;
   }
 
+  // Wait on host memory until every column's iterate after update k has been tested or the column has ended
+  // (wait_tested of the single-column loop, per column); fills B.h_scal from the mirrors
+  static int wait_tested(hf_ctx* ctx, int k, bool* all_done, int* max_iters, bool* breakdown) {
+    static const double limit_s = std::getenv("HEATFLOW_POLL_TIMEOUT_S") ? std::atof(std::getenv("HEATFLOW_POLL_TIMEOUT_S")) : 60.0;
+    hf_ctx::Batch& B = ctx->batch;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto reached = [&]() {
+      for (int j = 0; j < NV; ++j)
+        if (__atomic_load_n(&B.h_mirror[j].tested, __ATOMIC_ACQUIRE) < k && __atomic_load_n(&B.h_mirror[j].done, __ATOMIC_ACQUIRE) == 0) return false;
+      return true;
+    };
+    for (unsigned spin = 1; !reached(); ++spin) {
+      if ((spin & 0xfff) != 0) continue;
+      if (hipStreamQuery(ctx->stream) == hipSuccess) {
+        if (reached()) break;
+        return fail(ctx, HF_ERR_HIP, "batched PCG progress: stream drained before the test of iteration %d ran (%s)", k, hipGetErrorString(hipGetLastError()));
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+        return fail(ctx, HF_ERR_HIP, "batched PCG progress: no convergence test within %.0f s (waiting for iteration %d)", limit_s, k);
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    *all_done = true; *max_iters = 0; *breakdown = false;
+    for (int j = 0; j < NV; ++j) {
+      const ScalMirror& m = B.h_mirror[j];
+      B.h_scal[j].iters = m.iters; B.h_scal[j].zz = m.zz; B.h_scal[j].bn2 = m.bn2;
+      B.h_scal[j].done = __atomic_load_n(&B.h_mirror[j].done, __ATOMIC_ACQUIRE);
+      if (!B.h_scal[j].done) *all_done = false;
+      if (B.h_scal[j].done == 2) *breakdown = true;
+      *max_iters = std::max(*max_iters, B.h_scal[j].iters);
+    }
+    return HF_OK;
+  }
+
   // PCG on all columns, started from B.u; iteration counts / residuals are left in B.h_scal
   static int pcg(hf_ctx* ctx, bool use_amg, double rtol, double atol, int max_it) {
     hf_ctx::Batch& B = ctx->batch;
+    if (B.h_mirror != nullptr)     // the previous solve has ended: nothing in flight writes the mirrors
+      for (int j = 0; j < NV; ++j) {
+        __atomic_store_n(&B.h_mirror[j].done, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&B.h_mirror[j].tested, -1, __ATOMIC_RELEASE);
+      }
     HF_HIP(hipMemsetAsync(B.scal, 0, sizeof(Scal) * NV, ctx->stream));
     if (!use_amg) {
       spmv<2>(ctx, Avals(ctx), B.u, B.r, B.part_rz, B.b, B.z, B.part_zz, B.part_bn, 0.0);
-      hipLaunchKernelGGL((kb_begin<NV>), dim3(1), dim3(TPB), 0, ctx->stream, B.Pb, rtol, atol, B.part_zz, B.part_bn, B.part_rz, B.scal, B.red);
+      hipLaunchKernelGGL((kb_begin<NV>), dim3(1), dim3(TPB), 0, ctx->stream, B.Pb, rtol, atol, B.part_zz, B.part_bn, B.part_rz, B.scal, B.red, B.d_mirror);
     } else {
       spmv<5>(ctx, Avals(ctx), B.u, B.r, nullptr, B.b, B.z, B.part_zz, B.part_bn, ctx->amg[0].omega);
       hipLaunchKernelGGL((kb_begin<NV>), dim3(1), dim3(TPB), 0, ctx->stream, B.Pb, rtol, atol, B.part_zz, B.part_bn,
-                         static_cast<const double*>(nullptr), B.scal, B.red);
+                         static_cast<const double*>(nullptr), B.scal, B.red, B.d_mirror);
       vcycle(ctx, 0);
     }
     HF_HIP(hipGetLastError());
     bool all_done = false, breakdown = false;
     int launched = 0, iters = 0;
+    if (use_amg && B.h_mirror != nullptr && poll_enabled()) {
+      // multigrid iterations queued one test ahead (see pcg_solve in hf_solver.hpp): the reduction that marks converged
+      // columns publishes every column's outcome, and the V-cycle that follows it gives the host the time to queue
+      // the next iteration
+      if (B.pred_iters <= 0) {
+        HF_TRY(wait_tested(ctx, 0, &all_done, &iters, &breakdown));
+        if (all_done) return HF_OK;
+      }
+      int burst = std::max(1, std::min(max_it, B.pred_iters - 2));
+      while (true) {
+        for (int k = 0; k < burst; ++k) iteration(ctx, true, (launched + k) & 1);
+        launched += burst;
+        HF_HIP(hipGetLastError());
+        HF_TRY(wait_tested(ctx, launched, &all_done, &iters, &breakdown));
+        if (all_done || breakdown || launched >= max_it) break;
+        burst = 1;
+      }
+      B.pred_iters = iters;
+      if (breakdown) return fail(ctx, HF_ERR_NOCONV, "batched PCG breakdown (p.Ap <= 0) in at least one column");
+      if (!all_done) return fail(ctx, HF_ERR_NOCONV, "batched PCG not converged in %d iterations", launched);
+      return HF_OK;
+    }
     if (B.pred_iters <= 0) {
       HF_TRY(read_scal(ctx, &all_done, &iters, &breakdown));
       if (all_done) return HF_OK;
@@ -663,7 +733,6 @@ struct BatchOps {
   static int step(hf_ctx* ctx, const double* g_dev, double rtol, double atol, int max_it) {
     hf_ctx::Batch& B = ctx->batch;
     const int nb = ctx->nbc;
-    const size_t vec = sizeof(double) * static_cast<size_t>(ctx->n) * NV;
     spmv<0>(ctx, ctx->d_M, B.u, B.b);
     if (nb > 0) {
       if (ctx->nlift_rows > 0) {
@@ -687,8 +756,7 @@ struct BatchOps {
     const int rc = pcg(ctx, use_amg, rtol, atol, max_it);
     if (rc == HF_OK) {   // (solution with zeroed Dirichlet entries, right-hand side) joins every column's basis
       const int slot = B.pnext;
-      HF_HIP(hipMemcpyAsync(B.pV[slot], B.u, vec, hipMemcpyDeviceToDevice, ctx->stream));
-      HF_HIP(hipMemcpyAsync(B.pF[slot], B.b, vec, hipMemcpyDeviceToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_copy2, dim3(1024), dim3(TPB), 0, ctx->stream, ctx->n * NV, B.u, B.pV[slot], B.b, B.pF[slot]);
       if (nb > 0)
         hipLaunchKernelGGL((kb_zero_bc<NV>), dim3((nb * NV + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, B.pV[slot]);
       B.pused[slot] = true;

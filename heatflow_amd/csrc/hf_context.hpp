@@ -203,6 +203,7 @@ struct hf_ctx {
     double *z = nullptr, *z2 = nullptr, *tmp = nullptr;
     double *part_pAp = nullptr, *part_rz = nullptr, *part_zz = nullptr, *part_bn = nullptr;
     Scal *scal = nullptr, *h_scal = nullptr;
+    ScalMirror *h_mirror = nullptr, *d_mirror = nullptr;   // per-column progress for the host (pinned + mapped), hf_batch_begin only
     BRed* red = nullptr;         // per-column reduced scalars
     std::vector<BatchLevel> lev;
     int Pb = 0, pred_iters = 0;

@@ -328,6 +328,12 @@ void launch_amg_iteration(hf_ctx* c, double* x, int parity) {
   vcycle(c, parity ^ 1, true);
 }
 
+// HEATFLOW_POLL=0: bursts + copy-back of the scalars instead of the polled, one-test-ahead loops (A/B and diagnosis)
+inline bool poll_enabled() {
+  static const bool on = !(std::getenv("HEATFLOW_POLL") && std::getenv("HEATFLOW_POLL")[0] == '0');
+  return on;
+}
+
 // device scalars = zero, with the address of the host mirror (complete on return)
 int reset_scal(hf_ctx* ctx) {
   *ctx->h_scal = Scal{};
@@ -412,7 +418,7 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
   HF_HIP(hipGetLastError());
 
   int launched = 0;
-  if (use_amg && !trace_res && ctx->amg.size() > 1) {   // (a one-level hierarchy has no V-cycle kernel that tests: bursts below)
+  if (use_amg && !trace_res && ctx->amg.size() > 1 && poll_enabled()) {   // (a one-level hierarchy has no V-cycle kernel that tests: bursts below)
     // Multigrid iterations are queued one test ahead: the first kernel of a V-cycle publishes the convergence test of
     // the iterate it starts from (ScalMirror), so the host learns the outcome while that cycle still has its other ten
     // kernels to run and has the next iteration queued before they finish - no copy, no synchronisation, no idle
