@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <vector>
 
 namespace amg {
@@ -85,7 +86,7 @@ inline std::vector<double> diagonal(const Csr& A) {
 // aggregate of their strongest aggregated neighbour (pass-1 state), pass 3 groups the rest.
 // Nodes without strong connections (Dirichlet rows, diagonally dominant rows) get agg = -1:
 // they take no coarse correction, the Jacobi smoother treats them.
-inline int aggregate(const Csr& A, const std::vector<double>& d, double theta, std::vector<int>& agg) {
+inline int aggregate(const Csr& A, const std::vector<double>& d, double theta, std::vector<int>& agg, bool attach_weak = false) {
   const int n = A.nrow;
   std::vector<int> sptr(static_cast<size_t>(n) + 1, 0), sidx;
   std::vector<double> sval;
@@ -126,6 +127,22 @@ inline int aggregate(const Csr& A, const std::vector<double>& d, double theta, s
     for (int k = sptr[i]; k < sptr[i + 1]; ++k)
       if (agg[sidx[k]] == -1) agg[sidx[k]] = na;
     ++na;
+  }
+  if (attach_weak) {
+    // pass 4: rows whose couplings all fall below the threshold still take a coarse correction - through the aggregate
+    // of their largest coupling (a new aggregate if that neighbour has none); only uncoupled rows (Dirichlet) stay out
+    for (int i = 0; i < n; ++i) {
+      if (agg[i] != -1) continue;
+      double best = 0.0;
+      int who = -1;
+      for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+        const int j = A.idx[k];
+        if (j != i && std::fabs(A.val[k]) > best) { best = std::fabs(A.val[k]); who = j; }
+      }
+      if (who < 0) continue;
+      if (agg[who] == -1) agg[who] = na++;
+      agg[i] = agg[who];
+    }
   }
   return na;
 }
@@ -248,6 +265,15 @@ struct Params {
   // Also fold the FINEST level's two smoothing sweeps into the transfer operators (Rt, GP as on the intermediate
   // levels): the preconditioner then never passes over the fine operator itself, only over (I - w D^-1 A) P and G.
   bool fuse_fine = false;
+  bool fuse_fine_down_only = false;   // with fuse_fine: only the down leg Rt_0 (the up leg stays explicit: P_0, post-smoothing sweep)
+  // study knobs (scripts/micro/amg_study.cpp); the defaults are the production values
+  double prolong_scale = 1.0;   // factor on the prolongator's damping 4/(3 rho)
+  int prolong_steps = 1;        // Jacobi steps applied to the tentative prolongator
+  double theta_decay = 0.5;     // strength threshold of level l = theta * theta_decay^l
+  bool verbose = false;
+  double theta_level[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // > 0: threshold of that level (study)
+  double theta_coarse = 0.0;    // > 0: strength threshold of every level below the finest
+  bool attach_weak = false;     // aggregate(): rows without a strong coupling join the aggregate of their largest coupling
 };
 
 // Build from the fine operator A0 (moved in; released after the first Galerkin product).
@@ -268,20 +294,31 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
     const bool last = A.nrow <= prm.coarse_size || lev + 1 >= prm.max_levels;
     if (!last) {
       std::vector<int> agg;
-      const int na = aggregate(A, d, prm.theta * std::pow(0.5, lev), agg);
+      double theta_l = (lev > 0 && prm.theta_coarse > 0.0) ? prm.theta_coarse : prm.theta * std::pow(prm.theta_decay, lev);
+      if (lev < 8 && prm.theta_level[lev] > 0.0) theta_l = prm.theta_level[lev];
+      const int na = aggregate(A, d, theta_l, agg, prm.attach_weak);
+      if (prm.verbose) {
+        int64_t none = 0, trivial = 0;
+        for (int i = 0; i < A.nrow; ++i) {
+          if (agg[i] < 0) { ++none; if (A.ptr[i + 1] - A.ptr[i] <= 1) ++trivial; }
+        }
+        std::fprintf(stderr, "[amg setup] level %d rows %d aggregates %d (ratio %.2f) without aggregate %lld (of which identity rows %lld) theta %.4f\n", lev, A.nrow, na,
+                     static_cast<double>(A.nrow) / std::max(na, 1), static_cast<long long>(none), static_cast<long long>(trivial), theta_l);
+      }
       if (na == 0 || na > 0.8 * A.nrow) {            // coarsening stalled: finish here
         L.A = std::move(A);
         H.levels.push_back(std::move(L));
         break;
       }
-      L.P = smoothed_prolongator(A, d, agg, na, 4.0 / (3.0 * rho));
+      L.P = smoothed_prolongator(A, d, agg, na, prm.prolong_scale * 4.0 / (3.0 * rho));
+      for (int s = 1; s < prm.prolong_steps; ++s) L.P = smoothed_by_product(L.P, spgemm(A, L.P), L.dinv, prm.prolong_scale * 4.0 / (3.0 * rho));
       L.R = transpose(L.P);
       Csr AP = spgemm(A, L.P);
       Csr Ac = spgemm(L.R, AP);
       if (lev > 0 || prm.fuse_fine) {                // fused legs of the cycle (intermediate levels; the finest on request)
         const Csr Pt = smoothed_by_product(L.P, AP, L.dinv, L.omega);
         L.Rt = transpose(Pt);
-        L.GP = fused_up_leg(A, L.dinv, L.omega, Pt);
+        if (lev > 0 || !prm.fuse_fine_down_only) L.GP = fused_up_leg(A, L.dinv, L.omega, Pt);
       }
       if (lev > 0) L.A = std::move(A);               // level 0's operator stays with the caller
       H.levels.push_back(std::move(L));

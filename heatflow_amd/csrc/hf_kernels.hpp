@@ -941,7 +941,10 @@ __global__ __launch_bounds__(TPB) void k_start_vector(int n, const double* __res
 // A-norm: G alpha = h with G_kl = V_k . F_l, h_k = V_k . f.  V_k holds u^k with its Dirichlet entries zeroed (so
 // every dot product runs over the free rows only), F_k the right-hand side b^k as it was.
 // ------------------------------------------------------------------------------------------
-constexpr int PROJ_MH = 6;                  // solutions kept
+#ifndef HF_PROJ_MH
+#define HF_PROJ_MH 6
+#endif
+constexpr int PROJ_MH = HF_PROJ_MH;         // solutions kept (macro: A/B builds)
 constexpr int PROJ_MT = PROJ_MH + MAXRESP;  // + boundary responses
 struct ProjVecs { const double* V[PROJ_MT]; int slot[PROJ_MT]; int m; };
 

@@ -90,13 +90,18 @@ int build_amg(hf_ctx* ctx) {
   amg::Params prm;
   if (const char* e = std::getenv("HEATFLOW_AMG_THETA")) prm.theta = std::atof(e);          // tuning knobs
   if (const char* e = std::getenv("HEATFLOW_AMG_COARSE")) prm.coarse_size = std::atoi(e);
+  if (const char* e = std::getenv("HEATFLOW_AMG_THETA_COARSE")) prm.theta_coarse = std::atof(e);
+  if (const char* e = std::getenv("HEATFLOW_AMG_THETA_DECAY")) prm.theta_decay = std::atof(e);
+  if (const char* e = std::getenv("HEATFLOW_AMG_ATTACH_WEAK")) prm.attach_weak = (e[0] != '0');
+  prm.verbose = std::getenv("HEATFLOW_DEBUG") != nullptr;
   if (const char* e = std::getenv("HEATFLOW_AMG_SMOOTH_SCALE")) prm.smooth_scale = std::atof(e);
   // Finest level through fused legs when the fine operator no longer fits the 256 MiB Infinity Cache: the explicit
   // sweeps read A three times per iteration, which is nearly free while A stays cache-resident (1M DOF: fused +2 %)
   // and the dominant HBM traffic once it does not (4M DOF: -9 %, 16M DOF: -8 % per iteration, same iteration counts)
-  ctx->amg_fuse0 = static_cast<size_t>(ctx->nnz) * 12 > (static_cast<size_t>(256) << 20);
-  if (const char* e = std::getenv("HEATFLOW_AMG_FUSE0")) ctx->amg_fuse0 = (e[0] != '0');
-  prm.fuse_fine = ctx->amg_fuse0;
+  ctx->amg_fuse0 = static_cast<size_t>(ctx->nnz) * 12 > (static_cast<size_t>(256) << 20) ? 1 : 2;
+  if (const char* e = std::getenv("HEATFLOW_AMG_FUSE0")) ctx->amg_fuse0 = std::atoi(e);
+  prm.fuse_fine = ctx->amg_fuse0 != 0;
+  prm.fuse_fine_down_only = ctx->amg_fuse0 == 2;
   if (!amg::build(std::move(A0), prm, H)) return fail(ctx, HF_ERR_STATE, "AMG set-up failed (non-positive diagonal or singular coarse operator)");
   const size_t nl = H.levels.size();
   ctx->amg.resize(nl);
@@ -110,8 +115,8 @@ int build_amg(hf_ctx* ctx) {
       L.dinv = ctx->d_dinv;
       if (nl > 1 && hl.Rt.nrow > 0) {            // fused finest level: GP's operand is [r; x_1] = d_r with the level-1 result behind it
         HF_TRY(upload_csr(ctx, hl.Rt, L.Rt, f32));
-        HF_TRY(upload_csr(ctx, hl.GP, L.GP, f32));
-        if (L.Rt.rpc == 0 || L.GP.rpc == 0) {    // too small for the LDS-staged kernel (the only one with the r.z epilogue): explicit sweeps
+        if (hl.GP.nrow > 0) HF_TRY(upload_csr(ctx, hl.GP, L.GP, f32));
+        if (L.Rt.rpc == 0 || (hl.GP.nrow > 0 && L.GP.rpc == 0)) {    // too small for the LDS-staged kernel (the only one with the convergence test / r.z epilogue): explicit sweeps
           free_dev_csr(L.Rt);
           free_dev_csr(L.GP);
         }
@@ -281,8 +286,8 @@ void vcycle(hf_ctx* c, int out_slot, bool test_convergence = false) {
     launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
     return;
   }
-  const bool fused0 = L0.GP.nrow > 0;
-  if (fused0) {
+  const bool fused0 = L0.GP.nrow > 0;     // both legs of the finest level fused
+  if (L0.Rt.nrow > 0) {
     // finest level through its fused legs: b_1 = Rt_0 r (pre-smoothing from zero, residual and restriction in one
     // operator; early exit if the update before it has converged)
     launch_stream<0>(c, L0.Rt, c->d_r, c->amg[1].b, nullptr, nullptr, test_convergence ? c->d_part_zz : nullptr);
