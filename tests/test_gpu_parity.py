@@ -771,6 +771,46 @@ def test_compressed_and_plain_column_streams_give_identical_results(hip, tmp_pat
     assert np.array_equal(out["1"]["iters"], out["0"]["iters"])
 
 
+@pytest.mark.gpu
+def test_polled_and_copied_back_loops_give_identical_results(hip, tmp_path):
+    """The multigrid-PCG loops queue iterations one convergence test ahead by polling the host-visible progress mirror
+    (default); HEATFLOW_POLL=0 keeps the bursts + copy-back of the scalars.  Same kernels in the same order on the
+    same data, so fields and iteration counts agree bit for bit - single-column and batched (affine family).  One
+    subprocess per setting: the switch is read once."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(os.path.join(ROOT, 'tests'))!r})\n"
+        "from conftest import build_case\n"
+        "from helpers import make_problem\n"
+        "from heatflow_amd import hip_backend as hb\n"
+        "cfg, stack, mesh = build_case('geballe_with_diamond', 4.0)\n"
+        "prob = make_problem(cfg, stack, mesh, precond=1, amg_reuse=True)\n"
+        "_, _, it = prob.run(12, time_varying=[prob.bcs[3]])\n"
+        "u = prob.state()\n"
+        "be = prob.backend\n"
+        "be.batch_begin(4, hb.BATCH_SHARED)\n"
+        "g = np.stack([np.repeat(prob.bc_values((s + 1) * prob.dt, [prob.bcs[3]])[:, None], 4, axis=1) + np.arange(4) for s in range(12, 18)])\n"
+        "for j in range(4): be.batch_set_state(j, u + j)\n"
+        "_, bit = be.batch_run(g, prob.rtol, prob.atol, prob.max_it, None)\n"
+        "ub = np.stack([be.batch_get_state(j) for j in range(4)])\n"
+        "be.batch_end()\n"
+        "np.savez(sys.argv[1], u=u, it=np.array(it), ub=ub, bit=np.array(bit))\n"
+        "prob.close()\n")
+    out = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, HEATFLOW_POLL=flag)
+        res = subprocess.run([sys.executable, str(script), str(tmp_path / f"o{flag}.npz")], env=env, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out[flag] = np.load(tmp_path / f"o{flag}.npz")
+    for key in ("u", "it", "ub", "bit"):
+        assert np.array_equal(out["1"][key], out["0"][key]), key
+    assert out["1"]["it"].max() >= 5 and out["1"]["bit"].max() >= 3
+
+
 def test_two_heated_lines_take_two_response_directions(hip, case_no_diamond_small):
     """Two independently driven Dirichlet lines (the two-sided extension): the second difference of the boundary
     vector spans two directions, the library learns exactly two responses and still reproduces the kind-0 answer."""
