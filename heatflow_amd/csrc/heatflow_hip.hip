@@ -58,6 +58,15 @@ int install_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int
   ctx->c16 = true;
   if (const char* e = std::getenv("HEATFLOW_SPMV_C16")) ctx->c16 = (e[0] != '0');
   if (static_cast<size_t>(ctx->max_chunk_nnz_s + ctx->max_cdict) * 8 > 64 * 1024) ctx->c16 = false;   // LDS window of the kernel
+  // own rows of a chunk contiguous in its sorted column list <=> every row stores its diagonal (P1 patterns do)
+  ctx->cdict_own = static_cast<int>(T.spmv.ptr.size()) == ctx->nchunks_s + 1;
+  for (int c = 0; c < ctx->nchunks_s && ctx->cdict_own; ++c) {
+    const int32_t r0 = c * TS, r1 = std::min<int32_t>(n, r0 + TS);
+    const int32_t* lo = T.spmv.dict.data() + T.spmv.ptr[c];
+    const int32_t* hi = T.spmv.dict.data() + T.spmv.ptr[c + 1];
+    const int32_t* at = std::lower_bound(lo, hi, r0);
+    ctx->cdict_own = hi - at >= r1 - r0 && at[0] == r0 && at[r1 - r0 - 1] == r1 - 1;
+  }
   ctx->max_blk_nnz = T.max_blk_nnz;
   if (static_cast<size_t>((ctx->max_blk_nnz + 1) & ~1) * 16 + (RBA + 1) * 4 > 160 * 1024)
     return fail(ctx, HF_ERR_ARG, "row block holds %d nonzeros: LDS slab too large", ctx->max_blk_nnz);

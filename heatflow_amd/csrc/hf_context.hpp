@@ -79,6 +79,7 @@ struct hf_ctx {
   int32_t *d_cdict_ptr = nullptr, *d_cdict = nullptr;
   uint16_t* d_cid = nullptr;
   int max_cdict = 0;
+  bool cdict_own = false;      // every chunk's own rows sit contiguously in its column list (each row stores its diagonal): the kernels take x[row] from the staged slice
   bool c16 = true;             // HEATFLOW_SPMV_C16=0 keeps the 32-bit column stream
   bool have_mesh = false, have_mat = false, assembled = false;
   double dt = 0.0;

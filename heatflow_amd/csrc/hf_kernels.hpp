@@ -584,7 +584,9 @@ __device__ __forceinline__ void mirror_publish(ScalMirror* m, double zz, int ite
   __hip_atomic_store(&m->tested, iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-struct ColComp { const int32_t* dptr; const int32_t* dict; const uint16_t* id; int xd_off; };
+// own != 0 (square operators whose rows all store their diagonal): the chunk's own rows are a contiguous run of its sorted
+// column list, so the row-wise operand x[row] of MODE 4 / 8 / 9 is taken from the staged slice instead of read again.
+struct ColComp { const int32_t* dptr; const int32_t* dict; const uint16_t* id; int xd_off; int own; };
 
 template <int MODE, bool C16 = false, typename VT = double>
 __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows per chunk, <= TS */,
@@ -598,6 +600,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
                                               int parity, ColComp comp) {
   extern __shared__ double sprod[];
   __shared__ double s4[TS / 64];
+  __shared__ int s_own;   // position of the chunk's first row in its column list (ColComp::own)
   // launches inside the PCG loop return at once after convergence; MODE 0 / 7 are also used outside it (right-hand
   // side, debug products), where the launcher passes no `scal`
   if ((MODE == 3 || MODE == 4 || MODE == 6 || MODE == 9) && scal->done) return;
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
       if (MODE == 2 || MODE == 4 || MODE == 5) e_d = dinv[prow];
       if (MODE == 6 || (MODE == 9 && !first9)) e_y = y[prow];
       if (MODE == 9 && !first9) e_p = pvec[prow];
-      if (MODE == 4 || MODE == 8 || MODE == 9) e_x = x[prow];
+      if ((MODE == 4 || MODE == 8 || MODE == 9) && !(C16 && comp.own)) e_x = x[prow];
     }
     if (C16) {
       // first batch of values / 16-bit ids is requested before the operand slice is staged, so both latencies overlap
@@ -680,8 +683,13 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
         v[u] = in ? static_cast<double>(vals[k + u * TS]) : 0.0;
         id[u] = in ? static_cast<int>(comp.id[k + u * TS]) : 0;
       }
-      for (int i = threadIdx.x; i < nd; i += TS) xd[i] = x[comp.dict[d0 + i]];
+      for (int i = threadIdx.x; i < nd; i += TS) {
+        const int c = comp.dict[d0 + i];
+        xd[i] = x[c];
+        if ((MODE == 4 || MODE == 8 || MODE == 9) && c == r0) s_own = i;
+      }
       __syncthreads();
+      if ((MODE == 4 || MODE == 8 || MODE == 9) && comp.own && pin) e_x = xd[s_own + (prow - r0)];
       while (k < k1) {
         const int kn = k + HF_UNROLL * TS;
         double vn[HF_UNROLL];

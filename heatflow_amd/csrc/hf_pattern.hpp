@@ -342,7 +342,7 @@ void launch_spmv(hf_ctx* c, const VT* vals, const double* x, double* y, double* 
                  hipEvent_t ev_stop = nullptr, int parity = 0) {
   // With events: the launch carries them (hipExtLaunchKernelGGL), so they bracket the kernel's own
   // execution on the device - the same interval rocprofv3 reports - not the launch gap before it.
-  const ColComp comp{c->d_cdict_ptr, c->d_cdict, c->d_cid, c->max_chunk_nnz_s};
+  const ColComp comp{c->d_cdict_ptr, c->d_cdict, c->d_cid, c->max_chunk_nnz_s, c->cdict_own ? 1 : 0};
 #define HF_SPMV_ARGS c->n, c->nchunks_s, static_cast<int>(TS), static_cast<const int32_t*>(c->d_rowptr),                    \
                      static_cast<const int32_t*>(c->d_colidx), vals, x, y, (MODE == 0 ? nullptr : c->d_scal), part0, bvec,  \
                      dinv ? dinv : static_cast<const double*>(c->d_dinv), pvec, part1, part2, w, c->P, parity, comp

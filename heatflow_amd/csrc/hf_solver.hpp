@@ -217,10 +217,10 @@ void launch_stream_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x,
                         static_cast<double*>(nullptr), static_cast<double*>(nullptr), conv_part, 0.0, npart, 0
   if (m.cid != nullptr)
     hipLaunchKernelGGL((k_spmv<SM, true, VT>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz + m.max_dict) * 8, c->stream,
-                       HF_STREAM_ARGS2, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz});
+                       HF_STREAM_ARGS2, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz, 0});
   else
     hipLaunchKernelGGL((k_spmv<SM, false, VT>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream,
-                       HF_STREAM_ARGS2, ColComp{nullptr, nullptr, nullptr, 0});
+                       HF_STREAM_ARGS2, ColComp{nullptr, nullptr, nullptr, 0, 0});
 #undef HF_STREAM_ARGS2
 }
 
@@ -241,10 +241,10 @@ void launch_vec_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, do
                        static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0.0, 0, 0
     if (m.cid != nullptr)
       hipLaunchKernelGGL((k_spmv<SM, true, VT>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz + m.max_dict) * 8, c->stream,
-                         HF_STREAM_ARGS, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz});
+                         HF_STREAM_ARGS, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz, 0});
     else
       hipLaunchKernelGGL((k_spmv<SM, false, VT>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz) * 8, c->stream,
-                         HF_STREAM_ARGS, ColComp{nullptr, nullptr, nullptr, 0});
+                         HF_STREAM_ARGS, ColComp{nullptr, nullptr, nullptr, 0, 0});
 #undef HF_STREAM_ARGS
     return;
   }
