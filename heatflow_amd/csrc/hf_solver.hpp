@@ -95,10 +95,13 @@ int build_amg(hf_ctx* ctx) {
   if (const char* e = std::getenv("HEATFLOW_AMG_ATTACH_WEAK")) prm.attach_weak = (e[0] != '0');
   prm.verbose = std::getenv("HEATFLOW_DEBUG") != nullptr;
   if (const char* e = std::getenv("HEATFLOW_AMG_SMOOTH_SCALE")) prm.smooth_scale = std::atof(e);
-  // Finest level through fused legs when the fine operator no longer fits the 256 MiB Infinity Cache: the explicit
-  // sweeps read A three times per iteration, which is nearly free while A stays cache-resident (1M DOF: fused +2 %)
-  // and the dominant HBM traffic once it does not (4M DOF: -9 %, 16M DOF: -8 % per iteration, same iteration counts)
-  ctx->amg_fuse0 = static_cast<size_t>(ctx->nnz) * 12 > (static_cast<size_t>(256) << 20) ? 1 : 2;
+  // Finest level of the V-cycle.  Its explicit form passes over A twice (residual after pre-smoothing, post-smoothing
+  // sweep) besides R_0 and P_0.  The fused down leg Rt_0 = R_0 (I - w A D^-1) replaces the residual pass and R_0 by one
+  // operator of ~45 entries per coarse row in single precision: faster at every size measured (1M DOF -6 %, 4M -10 %,
+  // 16M -10 % per step against the explicit form).  The fused up leg GP_0 (~16 entries per fine row against A's 7) only
+  // pays once A streams from HBM far beyond the Infinity Cache: 1M +7 %, 4M +12 %, 16M -5 % against the down leg alone.
+  // Same iteration counts in all three forms (the same preconditioner in exact arithmetic).
+  ctx->amg_fuse0 = static_cast<size_t>(ctx->nnz) * 12 > (static_cast<size_t>(1) << 30) ? 1 : 2;
   if (const char* e = std::getenv("HEATFLOW_AMG_FUSE0")) ctx->amg_fuse0 = std::atoi(e);
   prm.fuse_fine = ctx->amg_fuse0 != 0;
   prm.fuse_fine_down_only = ctx->amg_fuse0 == 2;

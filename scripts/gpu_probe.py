@@ -20,9 +20,10 @@ be = prob.backend
 print("setup %.2fs  n=%d ne=%d nnz=%d nbc=%d  assemble(+bc) gpu ms=%.3f" % (time.time() - t0, be.n, be.n_e, be.nnz, be.n_bc, be.last_gpu_ms()), flush=True)
 n, nnz, ne = be.n, be.nnz, be.n_e
 if precond: print("amg", be.amg_info(), flush=True)
-times, samples, iters = prob.run(nsteps, watcher_nodes=None, time_varying=[prob.bcs[3]])
+prob.run(5, watcher_nodes=None, time_varying=[prob.bcs[3]])          # steps 0..4: boundary values still at the initial temperature
+times, samples, iters = prob.run(nsteps, watcher_nodes=None, time_varying=[prob.bcs[3]], first_step=5)
 ms = be.last_gpu_ms()
-print("run %d steps: %.2f ms total, %.3f ms/step, iters %s" % (nsteps, ms, ms / nsteps, list(iters)), flush=True)
+print("run steps 5..%d: %.2f ms total, %.3f ms/step, iters %s" % (4 + nsteps, ms, ms / nsteps, [int(i) for i in iters]), flush=True)
 tot_it = int(np.sum(iters))
 print("  per PCG iteration (incl. rhs etc): %.2f us" % (1e3 * ms / max(tot_it, 1)))
 names = {hb.K_SPMV: ("spmv", 12 * nnz + 20 * n), hb.K_PCG_SPMV: ("pcg_spmv", 12 * nnz + 44 * n), hb.K_PCG_UPDATE: ("pcg_update", 64 * n),

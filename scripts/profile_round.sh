@@ -8,8 +8,8 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-C3ARGS="--steps 20 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0"
-HBMARGS="--scale 0.1075 --precond jacobi --steps 2 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 0 --profile-steps 1"
+C3ARGS="--steps 20 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 3 --device-warmup-s 0.5"
+HBMARGS="--scale 0.1075 --precond jacobi --steps 2 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 0 --profile-steps 1 --device-warmup-s 0.5"
 for what in "$@"; do
   case $what in
     c3)
