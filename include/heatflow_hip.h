@@ -31,6 +31,9 @@
  *     (axial), mesh y = r (radial), weight r = x[1] as in run_with_diamond.py:321-322.
  *   - One ctx = one HIP device + one stream.  A ctx is not thread-safe; different
  *     ctxs may be driven from different threads or processes (one per GPU).
+ *   - hf_step / hf_run / hf_batch_run block until their steps are done; meanwhile the calling
+ *     thread polls pinned host memory that the solver kernels update (no other thread is
+ *     created).  No progress for HEATFLOW_POLL_TIMEOUT_S seconds (default 60) -> HF_ERR_HIP.
  *   - There is no CPU fallback: without a HIP device hf_create fails.
  */
 #ifndef HEATFLOW_HIP_H
