@@ -10,6 +10,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -310,16 +311,25 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
         H.levels.push_back(std::move(L));
         break;
       }
+      const auto tp0 = std::chrono::steady_clock::now();
+      auto lap = [&](const char* what) {
+        if (prm.verbose) std::fprintf(stderr, "[amg setup] level %d %-22s %.3f s\n", lev, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count());
+      };
       L.P = smoothed_prolongator(A, d, agg, na, prm.prolong_scale * 4.0 / (3.0 * rho));
       for (int s = 1; s < prm.prolong_steps; ++s) L.P = smoothed_by_product(L.P, spgemm(A, L.P), L.dinv, prm.prolong_scale * 4.0 / (3.0 * rho));
+      lap("prolongator");
       L.R = transpose(L.P);
+      lap("+ transpose");
       Csr AP = spgemm(A, L.P);
+      lap("+ A P");
       Csr Ac = spgemm(L.R, AP);
+      lap("+ R (A P)");
       if (lev > 0 || prm.fuse_fine) {                // fused legs of the cycle (intermediate levels; the finest on request)
         const Csr Pt = smoothed_by_product(L.P, AP, L.dinv, L.omega);
         L.Rt = transpose(Pt);
         if (lev > 0 || !prm.fuse_fine_down_only) L.GP = fused_up_leg(A, L.dinv, L.omega, Pt);
       }
+      lap("+ fused legs");
       if (lev > 0) L.A = std::move(A);               // level 0's operator stays with the caller
       H.levels.push_back(std::move(L));
       A = std::move(Ac);

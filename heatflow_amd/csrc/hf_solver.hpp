@@ -105,7 +105,12 @@ int build_amg(hf_ctx* ctx) {
   if (const char* e = std::getenv("HEATFLOW_AMG_FUSE0")) ctx->amg_fuse0 = std::atoi(e);
   prm.fuse_fine = ctx->amg_fuse0 != 0;
   prm.fuse_fine_down_only = ctx->amg_fuse0 == 2;
+  auto lap = [&](const char* what) {
+    if (prm.verbose) std::fprintf(stderr, "[amg setup] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  };
+  lap("operator downloaded");
   if (!amg::build(std::move(A0), prm, H)) return fail(ctx, HF_ERR_STATE, "AMG set-up failed (non-positive diagonal or singular coarse operator)");
+  lap("+ host hierarchy");
   const size_t nl = H.levels.size();
   ctx->amg.resize(nl);
   for (size_t l = 0; l < nl; ++l) {
@@ -160,6 +165,7 @@ int build_amg(hf_ctx* ctx) {
       show("Rt", l, ctx->amg[l].Rt); show("GP", l, ctx->amg[l].GP);
     }
   }
+  lap("+ operators uploaded");
   // coarsest level: dense inverse by Gauss-Jordan on the device
   ctx->coarse_n = 0;
   if (nl > 1 && H.coarse_n > 0 && H.coarse_n <= 4096) {
@@ -200,6 +206,7 @@ int build_amg(hf_ctx* ctx) {
     ctx->coarse_ld = ld;
     ctx->coarse_n = nc;
   }
+  lap("+ dense inverse");
   ctx->amg_opc = H.op_complexity;
   ctx->amg_ready = true;
   ctx->amg_setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
