@@ -19,8 +19,8 @@
 namespace {
 
 // Sum over the threads of a 256-thread block that serve the same column j = threadIdx.x % NV, fixed order.
-template <int NV>
-__device__ __forceinline__ double block_colsum(double v, double* sw /* [4 * NV] */) {
+template <int NV, int NW = 4>
+__device__ __forceinline__ double block_colsum(double v, double* sw /* [NW * NV], NW = wavefronts of the block */) {
 #pragma unroll
   for (int o = 32; o >= NV; o >>= 1) v += __shfl_down(v, o, 64);
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -29,7 +29,7 @@ __device__ __forceinline__ double block_colsum(double v, double* sw /* [4 * NV] 
   const int j = threadIdx.x % NV;
   double t = sw[j];
 #pragma unroll
-  for (int k = 1; k < 4; ++k) t += sw[k * NV + j];
+  for (int k = 1; k < NW; ++k) t += sw[k * NV + j];
   __syncthreads();
   return t;
 }
@@ -102,14 +102,15 @@ __device__ __forceinline__ double op_value(const BOp& op, size_t k, int j) {
 }
 
 // Fine-pattern SpMV on NV interleaved columns, thread = (row, column).  Modes as k_spmv (0, 2, 3, 4, 5, 8, 9).
+constexpr int KB_BT = 512;   // threads per workgroup of kb_spmv: 32 wavefronts per CU with the <= 1024 workgroups of a launch
 template <int MODE, int NV, int OPK>
-__global__ __launch_bounds__(TPB) void kb_spmv(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+__global__ __launch_bounds__(KB_BT) void kb_spmv(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                                const BOp op, const double* __restrict__ x, double* __restrict__ y,
                                                Scal* __restrict__ scal, double* __restrict__ part0, const double* __restrict__ bvec,
                                                const double* __restrict__ dinv, double* __restrict__ pvec, double* __restrict__ part1,
                                                double* __restrict__ part2, double w, const BRed* __restrict__ red, int parity) {
-  __shared__ double sw[4 * NV];
-  constexpr int RPB = TPB / NV;
+  __shared__ double sw[(KB_BT / 64) * NV];
+  constexpr int RPB = KB_BT / NV;
   const int j = threadIdx.x % NV, rl = threadIdx.x / NV;
   Scal* sc = scal + j;
   bool active = true;
@@ -189,12 +190,12 @@ __global__ __launch_bounds__(TPB) void kb_spmv(int n, const int32_t* __restrict_
     }
   }
   if (MODE == 2 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {
-    const double t0 = block_colsum<NV>(acc0, sw);
+    const double t0 = block_colsum<NV, KB_BT / 64>(acc0, sw);
     if (rl == 0) part0[j * MAXP + blockIdx.x] = t0;
   }
   if (MODE == 2 || MODE == 5) {
-    const double t1 = block_colsum<NV>(acc1, sw);
-    const double t2 = block_colsum<NV>(acc2, sw);
+    const double t1 = block_colsum<NV, KB_BT / 64>(acc1, sw);
+    const double t2 = block_colsum<NV, KB_BT / 64>(acc2, sw);
     if (rl == 0) { part1[j * MAXP + blockIdx.x] = t1; part2[j * MAXP + blockIdx.x] = t2; }
   }
 }
@@ -542,10 +543,10 @@ struct BatchOps {
     if (vals == c->d_M) {
       BOp m{};
       m.v0 = c->d_M;
-      hipLaunchKernelGGL((kb_spmv<MODE, NV, OP_SHARED>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, c->d_rowptr, c->d_colidx, m, x, y,
+      hipLaunchKernelGGL((kb_spmv<MODE, NV, OP_SHARED>), dim3(B.Pb), dim3(KB_BT), 0, c->stream, c->n, c->d_rowptr, c->d_colidx, m, x, y,
                          B.scal, part0, bvec, c->d_dinv, pvec, part1, part2, w, B.red, parity);
     } else {
-      hipLaunchKernelGGL((kb_spmv<MODE, NV, OPK>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, c->d_rowptr, c->d_colidx, Aop(c), x, y,
+      hipLaunchKernelGGL((kb_spmv<MODE, NV, OPK>), dim3(B.Pb), dim3(KB_BT), 0, c->stream, c->n, c->d_rowptr, c->d_colidx, Aop(c), x, y,
                          B.scal, part0, bvec, Dinv(c), pvec, part1, part2, w, B.red, parity);
     }
   }
