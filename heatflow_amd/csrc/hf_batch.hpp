@@ -102,6 +102,10 @@ __device__ __forceinline__ double op_value(const BOp& op, size_t k, int j) {
 }
 
 // Fine-pattern SpMV on NV interleaved columns, thread = (row, column).  Modes as k_spmv (0, 2, 3, 4, 5, 8, 9).
+#ifndef HF_KB_U
+#define HF_KB_U 4
+#endif
+constexpr int KB_U = HF_KB_U;  // products per batch of predicated loads in kb_spmv
 constexpr int KB_BT = 512;   // threads per workgroup of kb_spmv: 32 wavefronts per CU with the <= 1024 workgroups of a launch
 template <int MODE, int NV, int OPK>
 __global__ __launch_bounds__(KB_BT) void kb_spmv(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
@@ -143,19 +147,19 @@ __global__ __launch_bounds__(KB_BT) void kb_spmv(int n, const int32_t* __restric
     if (MODE == 9 && !first9) { e_y = y[o]; e_p = pvec[o]; }
     if (MODE == 4 || MODE == 8 || MODE == 9) e_x = x[o];
     double s = 0.0;
-    for (int k = k0; k < k1; k += 4) {
-      int c[4];
-      double v[4], xv[4];
+    for (int k = k0; k < k1; k += KB_U) {
+      int c[KB_U];
+      double v[KB_U], xv[KB_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < KB_U; ++u) {
         const bool in = k + u < k1;
         c[u] = in ? colidx[k + u] : 0;
         v[u] = in ? op_value<OPK, NV>(op, static_cast<size_t>(k + u), j) : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xv[u] = (k + u < k1) ? x[static_cast<size_t>(c[u]) * NV + j] : 0.0;
+      for (int u = 0; u < KB_U; ++u) xv[u] = (k + u < k1) ? x[static_cast<size_t>(c[u]) * NV + j] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s += v[u] * xv[u];
+      for (int u = 0; u < KB_U; ++u) s += v[u] * xv[u];
     }
     if (MODE == 0) {
       y[o] = s;
