@@ -253,6 +253,26 @@ def test_not_converged_is_reported(hip, case_no_diamond_small):
         prob.close()
 
 
+def test_multigrid_loop_reports_non_convergence_and_recovers(hip, case_with_diamond_small):
+    """The polled multigrid loop with too few iterations allowed: NotConverged with the iteration count in the message;
+    the same context then runs on normally (the progress mirror of the failed solve does not leak into the next one:
+    a stale `done` would end it after zero iterations, a stale counter would stall it)."""
+    cfg, stack, mesh = case_with_diamond_small
+    prob = make_problem(cfg, stack, mesh, precond=1)
+    try:
+        prob.run(8, time_varying=[prob.bcs[3]])
+        g = prob.bc_values(9 * prob.dt, [prob.bcs[3]])
+        with pytest.raises(hip.NotConverged, match="not converged in 2 iterations"):
+            prob.backend.step(g, prob.rtol, 0.0, 2)
+        g = prob.bc_values(10 * prob.dt, [prob.bcs[3]])
+        it, res = prob.backend.step(g, prob.rtol, 0.0, prob.max_it)
+        assert 3 <= it <= 40 and res <= prob.rtol
+        _, _, iters = prob.run(4, time_varying=[prob.bcs[3]], first_step=10)
+        assert (np.asarray(iters) >= 3).all() and np.isfinite(prob.state()).all()
+    finally:
+        prob.close()
+
+
 def test_amg_cuts_iterations_and_frozen_hierarchy_survives_a_kappa_change(hip, case_with_diamond_small):
     """Same answer with ~10x fewer iterations; with reuse=True a kappa change re-values only the
     fine operator (coarse levels frozen) and the result still matches the oracle."""
