@@ -31,13 +31,21 @@ class P1Space:
 
 
 class RowDirichletBC:
-    def __init__(self, V, location, *, coord=None, length=None, center=None, width=1e-10, value=0.0):
+    def __init__(self, V, location, *, coord=None, length=None, center=None, width=1e-10, value=0.0, row_dofs=None):
+        """``row_dofs`` (not in the reference): the DOF set of an earlier BC with the same location arguments on
+        the same space - a sweep locates each edge once instead of once per point."""
         self.V = V if hasattr(V, "coords") else P1Space(V)
         xy = self.V.coords
         self.width = float(width)
         self.center = center
         self.length = length
         self.location = location
+        if row_dofs is not None:
+            if location in ("x", "y") and center is None:
+                raise ValueError("row_dofs needs an explicit center for location 'x' / 'y'")
+            self.row_dofs = np.ascontiguousarray(row_dofs, dtype=np.int32)
+            self._finish(xy, value)
+            return
 
         x0, x1 = xy[:, 0], xy[:, 1]
         xmin, xmax, ymin, ymax = x0.min(), x0.max(), x1.min(), x1.max()
@@ -76,6 +84,9 @@ class RowDirichletBC:
             raise ValueError("Unknown location keyword.")
 
         self.row_dofs = np.nonzero(mask)[0].astype(np.int32)
+        self._finish(xy, value)
+
+    def _finish(self, xy, value):
         if self.row_dofs.size == 0:
             raise RuntimeError("No DOFs found for requested BC location/length.")
         self.dof_coords = xy[self.row_dofs]
@@ -133,11 +144,21 @@ def merge_bcs(bc_list):
     return dofs, owner[dofs], pos[dofs]
 
 
-def gather_bc_values(bc_list, owner, pos):
-    """Current values of the merged DOF list (after each bc.update(t))."""
+def gather_plan(n_bcs, owner, pos):
+    """Per BC the positions it fills in the merged list and the entries of its values that go there."""
+    plan = []
+    for k in range(n_bcs):
+        sel = np.nonzero(owner == k)[0]
+        plan.append((sel, pos[sel]))
+    return plan
+
+
+def gather_bc_values(bc_list, owner, pos, plan=None):
+    """Current values of the merged DOF list (after each bc.update(t)); ``plan`` = gather_plan(...) computed once."""
     g = np.empty(owner.shape, dtype=np.float64)
-    for k, bc in enumerate(bc_list):
-        sel = owner == k
-        if sel.any():
-            g[sel] = bc.values[pos[sel]]
+    if plan is None:
+        plan = gather_plan(len(bc_list), owner, pos)
+    for bc, (sel, src) in zip(bc_list, plan):
+        if sel.size:
+            g[sel] = bc.values[src]
     return g

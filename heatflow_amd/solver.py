@@ -16,7 +16,7 @@ import time
 import numpy as np
 from scipy.spatial import cKDTree
 
-from .bc import gather_bc_values, merge_bcs
+from .bc import gather_bc_values, gather_plan, merge_bcs
 from .hip_backend import ASM_ROW_GATHER, PC_AMG, PC_JACOBI, HeatflowHIP
 
 # Default PCG tolerance: at rtol = 1e-10 the temperature field agrees with a sparse
@@ -98,7 +98,9 @@ class HeatProblem:
         only the heated line, run_with_diamond.py:458-459, 472)."""
         for bc in (self.bcs if only is None else only):
             bc.update(t)
-        return gather_bc_values(self.bcs, self._owner, self._pos)
+        if getattr(self, "_plan", None) is None or len(self._plan) != len(self.bcs):
+            self._plan = gather_plan(len(self.bcs), self._owner, self._pos)
+        return gather_bc_values(self.bcs, self._owner, self._pos, self._plan)
 
     # -- stepping --------------------------------------------------------------------------
     def set_state(self, u):
