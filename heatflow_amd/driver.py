@@ -32,6 +32,13 @@ import time
 import numpy as np
 import yaml
 
+_YAML_DUMPER = getattr(yaml, "CSafeDumper", yaml.SafeDumper)     # libyaml when PyYAML was built with it (10x faster)
+
+
+def _dump_yaml(obj, f):
+    yaml.dump(obj, f, Dumper=_YAML_DUMPER)
+
+
 from .bc import P1Space, RowDirichletBC
 from .geometry import stack_no_diamond, stack_with_diamond
 from .heating import HeatingCurve
@@ -102,7 +109,7 @@ def prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack):
         mesh_cfg = copy.deepcopy(cfg)
         mesh_cfg["material_tags"] = tag_map
         with open(mesh_cfg_path, "w") as f:
-            yaml.safe_dump(mesh_cfg, f)
+            _dump_yaml(mesh_cfg, f)
         mesh.write(mesh_file_path)
         return mesh.coords, mesh.tris, mesh.tags, tag_map
     missing = [nm for nm, p in (("mesh.msh", mesh_file_path), ("mesh_cfg.yaml", mesh_cfg_path)) if not os.path.isfile(p)]
@@ -502,7 +509,7 @@ def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_me
             save_folder = output_folder
             os.makedirs(save_folder, exist_ok=True)
             with open(os.path.join(save_folder, "used_config.yaml"), "w") as f:
-                yaml.safe_dump(cfg, f)
+                _dump_yaml(cfg, f)
         else:
             save_folder = os.path.join(os.getcwd(), "sim_outputs", "refactor_test")
             os.makedirs(save_folder, exist_ok=True)
@@ -550,7 +557,7 @@ def run_simulation_batch_impl(kind, cfgs, output_folders, watcher_points_list, s
         for cfg, folder in zip(cfgs, output_folders):
             os.makedirs(folder, exist_ok=True)
             with open(os.path.join(folder, "used_config.yaml"), "w") as f:
-                yaml.safe_dump(cfg, f)
+                _dump_yaml(cfg, f)
         results = session.run_batch(cfgs, stacks, watcher_points_list[0])
         for res, folder, wp in zip(results, output_folders, watcher_points_list):
             if wp is not None:
