@@ -78,7 +78,7 @@ def parse_args(argv=None):
                     help="c3 workload: also run this many kappa points of the C5 sweep as a side measurement (0 = skip)")
     ap.add_argument("--sweep-concurrent", type=int, default=SWEEP_CONCURRENT)
     ap.add_argument("--sweep-batch", type=int, default=SWEEP_BATCH,
-                    help="sweep points advanced together by the batched time loop (8, 4, 2; 1 = one run per point)")
+                    help="sweep points advanced together by the batched time loop (16, 8, 4, 2; 1 = one run per point)")
     ap.add_argument("--hbm-scale", type=float, default=HBM_SCALE,
                     help="mesh factor of the HBM-resident roofline point (N = 1 only; 0 = skip)")
     ap.add_argument("--rendezvous-only", action="store_true",

@@ -805,7 +805,7 @@ int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, doubl
 int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t operator_kind) {
   if (!ctx) return HF_ERR_ARG;
   if (!ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_batch_begin before hf_assemble");
-  if (nv != 2 && nv != 4 && nv != 8) return fail(ctx, HF_ERR_ARG, "hf_batch_begin: 2, 4 or 8 columns (got %d)", nv);
+  if (nv != 2 && nv != 4 && nv != 8 && nv != 16) return fail(ctx, HF_ERR_ARG, "hf_batch_begin: 2, 4, 8 or 16 columns (got %d)", nv);
   if (operator_kind < 0 || operator_kind > 2) return fail(ctx, HF_ERR_ARG, "hf_batch_begin: unknown operator kind %d", operator_kind);
   if (operator_kind == HF_BATCH_PER_COLUMN && ctx->precond == 1 && !ctx->amg_reuse)
     return fail(ctx, HF_ERR_STATE, "hf_batch_begin: per-column operators need the frozen hierarchy (hf_set_precond(1, reuse = 1))");
@@ -951,12 +951,13 @@ int hf_batch_set_affine(hf_ctx* ctx, int32_t n_tags, const int32_t* tags, const 
   for (int j = 0; j < B.nv; ++j) B.delta[j] = delta[j];
   BOp op{};
   op.v0 = ctx->d_A; op.v1 = B.A1;
-  for (int j = 0; j < 8; ++j) op.delta[j] = B.delta[j];
+  for (int j = 0; j < NV_MAX; ++j) op.delta[j] = B.delta[j];
   const int thr = ctx->n * B.nv;
   switch (B.nv) {
     case 2: hipLaunchKernelGGL((kb_affine_dinv<2>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, ctx->d_rowptr, ctx->d_colidx, op, B.dinv); break;
     case 4: hipLaunchKernelGGL((kb_affine_dinv<4>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, ctx->d_rowptr, ctx->d_colidx, op, B.dinv); break;
-    default: hipLaunchKernelGGL((kb_affine_dinv<8>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, ctx->d_rowptr, ctx->d_colidx, op, B.dinv); break;
+    case 8: hipLaunchKernelGGL((kb_affine_dinv<8>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, ctx->d_rowptr, ctx->d_colidx, op, B.dinv); break;
+    default: hipLaunchKernelGGL((kb_affine_dinv<16>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, ctx->d_rowptr, ctx->d_colidx, op, B.dinv); break;
   }
   HF_HIP(hipGetLastError());
   HF_HIP(hipStreamSynchronize(ctx->stream));
@@ -1032,7 +1033,8 @@ int hf_batch_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol,
       switch (nv) {
         case 2: hipLaunchKernelGGL((kb_gather<2>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, B.u, out); break;
         case 4: hipLaunchKernelGGL((kb_gather<4>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, B.u, out); break;
-        default: hipLaunchKernelGGL((kb_gather<8>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, B.u, out); break;
+        case 8: hipLaunchKernelGGL((kb_gather<8>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, B.u, out); break;
+        default: hipLaunchKernelGGL((kb_gather<16>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, B.u, out); break;
       }
     }
   }

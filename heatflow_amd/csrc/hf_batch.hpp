@@ -4,7 +4,7 @@
 // hierarchy) every coarse operator of the multigrid preconditioner; they differ in the boundary values (fwhm
 // sweeps: even the fine operator A is shared) and / or in the values of A (kappa sweeps).  Reference: the grid of
 // parameter_sweep.py:195-235 and the kappa list of sweep_test.py:47-52, which the reference farms out as
-// independent runs.  Here NV points (2, 4 or 8) are the columns of one multi-vector PCG:
+// independent runs.  Here NV points (2, 4, 8 or 16) are the columns of one multi-vector PCG:
 //   * every vector is stored interleaved, x[i * NV + j] = entry i of column j, so a gather of x[col] fetches the
 //     NV columns as one contiguous 8*NV-byte segment and every index / shared value is read once for NV products;
 //   * the fine operator is either shared (one value per nonzero) or per column (values interleaved like vectors);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(TPB) void kb_reduce(int P, int nv, const double* __
 //   OP_AFFINE  A_j = A + d_j A1   two shared value arrays and one scalar per column: a sweep over the conductivity of
 //                                 one material (or of materials that move together), A1 = dt K restricted to it
 enum { OP_SHARED = 0, OP_PERCOL = 1, OP_AFFINE = 2 };
-struct BOp { const double* v0; const double* v1; double delta[8]; };
+struct BOp { const double* v0; const double* v1; double delta[NV_MAX]; };
 
 template <int OPK, int NV>
 __device__ __forceinline__ double op_value(const BOp& op, size_t k, int j) {
@@ -525,7 +525,7 @@ struct BatchOps {
     BOp o{};
     o.v0 = B.sysA ? B.sysA : (OPK == OP_PERCOL ? B.A : c->d_A);
     o.v1 = B.A1;
-    for (int j = 0; j < 8; ++j) o.delta[j] = B.delta[j];
+    for (int j = 0; j < NV_MAX; ++j) o.delta[j] = B.delta[j];
     return o;
   }
   static BOp Liftop(hf_ctx* c) {
@@ -533,7 +533,7 @@ struct BatchOps {
     BOp o{};
     o.v0 = OPK == OP_PERCOL ? B.lift_val : c->d_lift_val;
     o.v1 = B.lift1;
-    for (int j = 0; j < 8; ++j) o.delta[j] = B.delta[j];
+    for (int j = 0; j < NV_MAX; ++j) o.delta[j] = B.delta[j];
     return o;
   }
   static const double* Avals(hf_ctx* c) { return c->d_A; }   // tag: "the system operator" (any pointer but d_M)
@@ -786,6 +786,9 @@ int batch_dispatch(hf_ctx* ctx, F&& f) {
     case 32: return f(BatchOps<8, OP_SHARED>());
     case 33: return f(BatchOps<8, OP_PERCOL>());
     case 34: return f(BatchOps<8, OP_AFFINE>());
+    case 64: return f(BatchOps<16, OP_SHARED>());
+    case 65: return f(BatchOps<16, OP_PERCOL>());
+    case 66: return f(BatchOps<16, OP_AFFINE>());
     default: return fail(ctx, HF_ERR_STATE, "no batch is open (hf_batch_begin)");
   }
 }

@@ -58,7 +58,8 @@ struct Scal {                  // device-resident PCG scalars
 };
 
 // Per-column scalars of the batched PCG (hf_batch.hpp), each reduced once per producer by a one-workgroup kernel
-struct BRed { double pAp[8], rz[2][8], zz[8], bn[8]; };
+constexpr int NV_MAX = 16;    // columns of the widest batch
+struct BRed { double pAp[NV_MAX], rz[2][NV_MAX], zz[NV_MAX], bn[NV_MAX]; };
 
 }  // namespace
 
@@ -198,7 +199,7 @@ struct hf_ctx {
     const double *sysA = nullptr, *sysDinv = nullptr;   // shared operator other than ctx->d_A (the flux projection's mass matrix)
     double *A = nullptr, *dinv = nullptr, *lift_val = nullptr;            // per-column operator data (opk 1; dinv also opk 2)
     double *A1 = nullptr, *lift1 = nullptr;                               // affine part and its lifting values (opk 2)
-    double delta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double delta[NV_MAX] = {};
     double *g = nullptr;                                                   // boundary values of all steps
     double *u = nullptr, *uprev = nullptr, *ustart = nullptr, *b = nullptr, *r = nullptr, *p = nullptr, *Ap = nullptr;
     double *z = nullptr, *z2 = nullptr, *tmp = nullptr;

@@ -242,13 +242,13 @@ class SimulationSession:
         return names, np.array([self._tree.query(p)[1] for p in coords_w], dtype=np.int32)
 
     def run_batch(self, cfgs, stacks, watcher_points=None):
-        """``len(cfgs)`` in (2, 4, 8) simulations of this mesh advanced together (hf_batch_*): the points of a
+        """``len(cfgs)`` in (2, 4, 8, 16) simulations of this mesh advanced together (hf_batch_*): the points of a
         sweep that share geometry, time stepping and rho_c; they may differ in the boundary values (fwhm,
         heating curve: one shared operator) and in the conductivities (one operator per column, shared
         frozen multigrid hierarchy).  Returns one result dict per configuration, as :meth:`run` does."""
         nv = len(cfgs)
-        if nv not in (2, 4, 8):
-            raise ValueError("run_batch: 2, 4 or 8 configurations at a time")
+        if nv not in (2, 4, 8, 16):
+            raise ValueError("run_batch: 2, 4, 8 or 16 configurations at a time")
         t_start = time.time()
         cfg0 = cfgs[0]
         num_steps = int(cfg0["timing"]["num_steps"])
@@ -546,7 +546,7 @@ def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_me
 
 
 def run_simulation_batch_impl(kind, cfgs, output_folders, watcher_points_list, session, suppress_print=True):
-    """``run_simulation`` for 2, 4 or 8 configurations of one resident mesh at once (SimulationSession.run_batch):
+    """``run_simulation`` for 2, 4, 8 or 16 configurations of one resident mesh at once (SimulationSession.run_batch):
     the same per-run artefacts (``used_config.yaml``, ``watcher_points.csv``) in each output folder, no XDMF,
     no read-flux projection.  Returns the list of result dicts."""
     with suppress_output(suppress_print):

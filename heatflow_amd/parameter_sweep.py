@@ -160,10 +160,10 @@ _EMPTY_MESH = (np.zeros((0, 2)), np.zeros((0, 3), np.int32), np.zeros(0, np.int3
 
 
 def batch_groups(items, batch):
-    """Split ``items`` into consecutive groups of 8, 4 or 2 (at most ``batch``) and singles: the group sizes the
+    """Split ``items`` into consecutive groups of 16, 8, 4 or 2 (at most ``batch``) and singles: the group sizes the
     batched time loop takes (hf_batch_begin)."""
     out, i = [], 0
-    sizes = [s for s in (8, 4, 2) if s <= max(int(batch), 1)]
+    sizes = [s for s in (16, 8, 4, 2) if s <= max(int(batch), 1)]
     while i < len(items):
         left = len(items) - i
         take = next((s for s in sizes if s <= left), 1)
@@ -233,7 +233,7 @@ def run_parameter_sweep(base_config_path, output_dir, fwhm_range, k_range, width
     """Sweep driver.  ``num_processes`` is accepted for signature parity; the degree of
     parallelism is the size of the torch.distributed world (one rank per GPU).
     ``session_factory(coords, tris, tags, tag_map)`` lets tests substitute the solver session.
-    ``batch`` > 1: up to that many (8, 4 or 2) consecutive points of a rank advance together through the batched
+    ``batch`` > 1: up to that many (16, 8, 4 or 2) consecutive points of a rank advance together through the batched
     time loop (points that share k share one operator, others get one operator per column)."""
     rank, world = world_info()
     with open(base_config_path) as f:
@@ -332,7 +332,7 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
     once, each rank keeps it resident and only re-values A per point.  Returns rows [{k, rmse, runtime,...}]
     (rmse of the normalised o-side watcher against the experiment, sweep_test.py:76-93).
 
-    ``batch`` > 1 advances up to that many (8, 4 or 2) of a rank's points together through the batched time loop
+    ``batch`` > 1 advances up to that many (16, 8, 4 or 2) of a rank's points together through the batched time loop
     (hf_batch_*: one operator per column, shared frozen multigrid hierarchy): at stock mesh sizes a single run is
     launch-bound, a batch of 8 costs little more than one run.
     ``concurrent`` > 1 runs that many of a rank's points (or batches) at once, each on its own solver context
@@ -395,7 +395,7 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
         return row
 
     def many_points(ks, sess):
-        """len(ks) in (2, 4, 8): one batched loop; every point is re-run on its own if the batch fails."""
+        """len(ks) in (2, 4, 8, 16): one batched loop; every point is re-run on its own if the batch fails."""
         cfgs = []
         for k in ks:
             c = copy.deepcopy(cfg)
@@ -493,7 +493,7 @@ def main(argv=None):
     p.add_argument("--write-xdmf", action="store_true")
     p.add_argument("--verbose", action="store_true")
     p.add_argument("--batch", type=int, default=8,
-                   help="points of a rank advanced together by the batched time loop (8, 4, 2; 1 = one run per point)")
+                   help="points of a rank advanced together by the batched time loop (16, 8, 4, 2; 1 = one run per point)")
     a = p.parse_args(argv)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch

@@ -171,7 +171,7 @@ int hf_step(hf_ctx* ctx, const double* g_bc, double rtol, double atol, int32_t m
 int hf_run(hf_ctx* ctx, int32_t n_steps, const double* g_bc_all, double rtol, double atol, int32_t max_it,
            int32_t n_s, const int32_t* nodes, double* samples, int32_t* iters);
 
-/* Batched time loop: nv = 2, 4 or 8 sweep points of ONE mesh, Dirichlet set and rho_c advance together as the
+/* Batched time loop: nv = 2, 4, 8 or 16 sweep points of ONE mesh, Dirichlet set and rho_c advance together as the
  * columns of a multi-vector PCG (reference: the independent runs of the parameter grid, parameter_sweep.py:195-235,
  * and of the kappa list, sweep_test.py:47-52).  Vectors are stored interleaved on the device, every index and every
  * shared matrix value is read once for nv products, and each column keeps its own alpha / beta / tolerance /

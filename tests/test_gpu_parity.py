@@ -1018,7 +1018,7 @@ def test_pattern_blob_export_and_prebuilt_install(hip, case_with_diamond_small):
 
 @pytest.mark.parametrize("kind", ["per_column", "affine"])
 @pytest.mark.parametrize("precond", [0, 1])
-@pytest.mark.parametrize("nv", [2, 4, 8])
+@pytest.mark.parametrize("nv", [2, 4, 8, 16])
 def test_batched_time_loop_with_per_column_operators_matches_single_runs_and_oracle(hip, nv, precond, kind, case_with_diamond_small):
     """hf_batch_*: nv kappa_sample values advance together as interleaved columns (per-column fine operator,
     shared frozen hierarchy).  Every column must match the oracle's run for its kappa at every step (<= 1e-4 K)
@@ -1135,7 +1135,7 @@ def test_batch_call_order_and_argument_errors(hip, case_with_diamond_small):
     prob = make_problem(cfg, stack, mesh, precond=1)              # hierarchy not frozen (amg_reuse = False)
     be = prob.backend
     try:
-        with pytest.raises(ValueError, match="2, 4 or 8"):
+        with pytest.raises(ValueError, match="2, 4, 8 or 16"):
             be.batch_begin(3)
         with pytest.raises(ValueError, match="unknown operator kind"):
             be.batch_begin(4, per_column_operator=5)
