@@ -32,6 +32,9 @@ refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
   holds the element kernel's variants.
 * cpu_baseline: the oracle (reference algorithm: assemble once, sparse LU once, two
   triangular solves per step; SciPy SuperLU, 1 thread) on the same mesh, rank 0, N = 1 only.
+* C5's CPU baseline (``cpu_baseline`` of workload sweep64, ``config.sweep64.cpu_farm_baseline`` of the default one):
+  8 of the 64 points through the oracle on a pool of one single-threaded process per point, as the reference farms
+  its points over ``mp.Pool`` (parameter_sweep.py:423-446).  It runs in a child process before this one touches the GPU.
 """
 import os
 
@@ -81,6 +84,10 @@ def parse_args(argv=None):
                     help="sweep points advanced together by the batched time loop (16, 8, 4, 2; 1 = one run per point)")
     ap.add_argument("--hbm-scale", type=float, default=HBM_SCALE,
                     help="mesh factor of the HBM-resident roofline point (N = 1 only; 0 = skip)")
+    ap.add_argument("--cpu-farm-points", type=int, default=8,
+                    help="C5 CPU baseline (N = 1 only): this many sweep points through the reference algorithm, one process per point "
+                         "(mirrors the reference's mp.Pool, parameter_sweep.py:423-446); 0 = skip.  Runs before anything touches the GPU")
+    ap.add_argument("--cpu-farm-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="form the process group, report its size and exit: checks the launcher plumbing (no GPU work)")
     args = ap.parse_args(argv)
@@ -169,6 +176,65 @@ def cpu_baseline(cfg, mesh, n_sample_steps, first_step):
                    f"LU factorisation {sol.t_factor:.1f} s"),
         "s_per_step": t_steps / n_sample_steps, "factor_s": sol.t_factor,
     }
+
+
+def _farm_point(job):
+    """One sweep point on one host core through the oracle (child of the farm process; GPU-free)."""
+    cfg, k, arrays, mtags = job
+    import copy
+    from oracle import heat_oracle as ho
+    c = copy.deepcopy(cfg)
+    c["mats"]["p_sample"]["k"] = float(k)
+    t0 = time.perf_counter()
+    ho.run_reference_algorithm(c, arrays[0], arrays[1], arrays[2], mtags, os.path.join(ROOT, c["heating"]["file"]),
+                               num_steps=int(c["timing"]["num_steps"]), watcher_nodes=[0])
+    return time.perf_counter() - t0
+
+
+def cpu_farm_worker(n_points, steps_per_point):
+    """Body of `bench.py --cpu-farm-worker` (a process of its own, started before the parent touches the GPU): mesh once,
+    then `n_points` kappa_sample points of BASELINE C5 on a pool of one process per point (at most the box's cores)."""
+    import multiprocessing as mp
+    import yaml
+    from heatflow_amd import parameter_sweep as ps
+    from heatflow_amd.geometry import build_stack
+    from heatflow_amd.mesh import Mesh
+
+    for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS", "NUMEXPR_NUM_THREADS"):   # parameter_sweep.py:46-53
+        os.environ[v] = "1"
+    with open(os.path.join(ROOT, "cfgs", "geballe_with_diamond.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    dt0 = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
+    cfg["timing"]["num_steps"] = int(steps_per_point)
+    cfg["timing"]["t_final"] = dt0 * int(steps_per_point)
+    stack = build_stack(cfg)
+    mesh = Mesh("mesh.msh", stack.bounds, stack.materials).build_mesh()
+    arrays, mtags = (mesh.coords, mesh.tris, mesh.tags), mesh.material_tags
+    ks = ps.get_k_values(count=64)[:n_points]
+    procs = max(1, min(n_points, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(procs) as pool:
+        per_point = pool.map(_farm_point, [(cfg, k, arrays, mtags) for k in ks], chunksize=1)
+    wall = time.perf_counter() - t0
+    n = len(mesh.coords)
+    print(json.dumps({
+        "value": n_points * n * steps_per_point / wall, "unit": "DOF-updates/s", "cores": procs, "kind": "port",
+        "sample": (f"{n_points} of the 64 kappa_sample points of BASELINE C5 (stock mesh, {n} DOF, {steps_per_point} steps each) through "
+                   f"oracle/heat_oracle.py (SciPy SuperLU, not FEniCS/MUMPS), one single-threaded process per point on {procs} of "
+                   f"{os.cpu_count()} host cores, each assembling and factorising for its point as the reference's pool workers do "
+                   f"(parameter_sweep.py:123-192); mesh built once and handed over; process start-up included"),
+        "wall_s": wall, "per_point_s_mean": float(sum(per_point) / len(per_point)), "points": n_points}))
+    return 0
+
+
+def run_cpu_farm(args, steps_per_point=100):
+    """Start the farm as a child process and return its JSON (None when it fails: the baseline is a report, not a gate)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-farm-worker", "--cpu-farm-points", str(args.cpu_farm_points), "--steps", str(steps_per_point)]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        return json.loads(p.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:          # noqa: BLE001 - reported in the JSON line
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 class Ranks:
@@ -389,8 +455,15 @@ def hbm_resident_point(scale, dev_index, steps):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.cpu_farm_worker:
+        return cpu_farm_worker(args.cpu_farm_points, args.steps or 100)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args, argv)
+    # C5's CPU baseline is a pool of processes: it runs to completion here, before this process touches the GPU
+    farm = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_farm_points > 0 and not args.rendezvous_only
+            and (args.workload == "sweep64" or (args.sweep_points > 0 and args.cpu_steps > 0))):
+        farm = run_cpu_farm(args, args.steps if args.workload == "sweep64" else 100)
 
     # stdout carries exactly ONE line (the JSON): everything else - RCCL's version banner, library
     # chatter - is sent to stderr by pointing fd 1 at fd 2 until the result is written
@@ -426,7 +499,9 @@ def main(argv=None):
             out = dict(common, metric="DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond", value=sw["value"],
                        ms_per_step=1e3 * sw["wall_s"] / args.steps, scaling="strong",
                        config={"workload": sw["workload"], **{k: v for k, v in sw.items() if k not in ("workload", "value", "unit")}},
-                       roofline=None, cpu_baseline=None)
+                       roofline=None, cpu_baseline=farm)
+            if farm and "value" in farm:
+                out["config"]["gpu_over_cpu_farm"] = sw["value"] / farm["value"]
             emit(out)
         ranks.close()
         return 0
@@ -549,6 +624,10 @@ def main(argv=None):
         if jacobi is not None:
             out["config"]["jacobi_pcg"] = jacobi
         if sweep is not None:
+            if farm:
+                sweep["cpu_farm_baseline"] = farm
+                if "value" in farm:
+                    sweep["gpu_over_cpu_farm"] = sweep["value"] / farm["value"]
             out["config"]["sweep64"] = sweep
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, mesh, args.cpu_steps, args.warmup)
