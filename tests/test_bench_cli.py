@@ -45,3 +45,13 @@ def test_more_ranks_than_gpus_fails_loudly_with_rccl():
 def test_bad_arguments_are_rejected():
     p = _run(["--gpus", "0"])
     assert p.returncode != 0
+
+
+def test_cpu_farm_worker_reports_a_pool_of_single_threaded_processes():
+    """C5's CPU baseline: the farm body (a GPU-free child of bench.py) runs sweep points through the oracle on a process
+    pool and prints one JSON object with the fields of `cpu_baseline`."""
+    p = _run(["--cpu-farm-worker", "--cpu-farm-points", "2", "--steps", "3"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["kind"] == "port" and out["cores"] == 2 and out["points"] == 2 and out["unit"] == "DOF-updates/s"
+    assert out["value"] > 0 and out["wall_s"] >= out["per_point_s_mean"] * 0.5
