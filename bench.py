@@ -619,6 +619,16 @@ def main(argv=None):
                                      "what": "16-byte-load read of the operator's values + column indices on this box",
                                      "frac_of_it": achieved / stream_gbs},
             "assembly": asm_roof, "hbm_resident": hbm}
+        if jacobi is not None:
+            # the whole Jacobi-PCG iteration = iteration head + update, 12*nnz + 84*n bytes, over the time the
+            # loop really spends per iteration (steps incl. right-hand side and start vector / iterations)
+            it_us = 1e3 * jacobi["ms_per_step"] / max(jacobi["pcg_iters_per_step_mean"], 1.0)
+            it_bytes = 12 * nnz + 84 * n
+            out["roofline"]["jacobi_pcg_iteration"] = {
+                "bytes": it_bytes, "formula": "12*nnz + 84*n (SURVEY 8d: SpMV + x, r, p read-modify-write + Ap, dinv reads)",
+                "us_per_iteration_in_loop": it_us, "achieved": it_bytes / (it_us * 1e-6) / 1e9,
+                "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "us_kernels_back_to_back": k_us["spmv9_back_to_back"] + k_us["update_back_to_back"]}
         if precond == 1:
             out["config"]["amg"] = amg_info
         if jacobi is not None:
