@@ -409,18 +409,26 @@ __global__ __launch_bounds__(TPB) void kb_proj_dots(int n, ProjVecs a, const dou
 #pragma unroll
   for (int k = 0; k < PROJ_MH; ++k) { ah[k] = 0.0; ag[k] = 0.0; }
   const int nrb = (n + RPB - 1) / RPB;
-  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
-    const int row = rb * RPB + rl;
-    if (row >= n) continue;
-    const size_t o = static_cast<size_t>(row) * NV + j;
-    const double fi = f[o], gi = Fnew ? Fnew[o] : 0.0;
+  // two row blocks per pass: the loads of both are in flight together (the stored vectors come from HBM)
+  for (int rb = blockIdx.x; rb < nrb; rb += 2 * gridDim.x) {
+    const int row = rb * RPB + rl, row2 = (rb + static_cast<int>(gridDim.x)) * RPB + rl;
+    const bool one = row < n, two = rb + static_cast<int>(gridDim.x) < nrb && row2 < n;
+    const size_t o = static_cast<size_t>(one ? row : 0) * NV + j, o2 = static_cast<size_t>(two ? row2 : 0) * NV + j;
+    const double fi = one ? f[o] : 0.0, gi = (one && Fnew) ? Fnew[o] : 0.0;
+    const double fj = two ? f[o2] : 0.0, gj = (two && Fnew) ? Fnew[o2] : 0.0;
+    double v0[PROJ_MH], v1[PROJ_MH];
 #pragma unroll
-    for (int k = 0; k < PROJ_MH; ++k)
-      if (k < a.m) {
-        const double v = a.V[k][o];
-        ah[k] += v * fi;
-        ag[k] += v * gi;
-      }
+    for (int k = 0; k < PROJ_MH; ++k) {
+      v0[k] = (k < a.m && one) ? a.V[k][o] : 0.0;
+      v1[k] = (k < a.m && two) ? a.V[k][o2] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < PROJ_MH; ++k) {
+      ah[k] += v0[k] * fi;
+      ag[k] += v0[k] * gi;
+      ah[k] += v1[k] * fj;
+      ag[k] += v1[k] * gj;
+    }
   }
 #pragma unroll
   for (int k = 0; k < PROJ_MH; ++k)
@@ -751,7 +759,7 @@ struct BatchOps {
     if (act.m > 0) {
       hipLaunchKernelGGL((kb_proj_dots<NV>), dim3(B.Pb), dim3(TPB), 0, ctx->stream, ctx->n, act, B.b,
                          B.ppending >= 0 ? B.pF[B.ppending] : static_cast<const double*>(nullptr), B.ppart);
-      hipLaunchKernelGGL(k_proj_solve, dim3(NV), dim3(TPB), 0, ctx->stream, B.Pb, act, B.ppending, 1, B.ppart, B.pG, B.palpha);
+      hipLaunchKernelGGL(k_proj_solve, dim3(NV), dim3(PROJ_SOLVE_T), 0, ctx->stream, B.Pb, act, B.ppending, 1, B.ppart, B.pG, B.palpha);
       B.ppending = -1;
       hipLaunchKernelGGL((kb_proj_combine<NV>), dim3(B.Pb), dim3(TPB), 0, ctx->stream, ctx->n, act, B.palpha, B.u);
       if (nb > 0)

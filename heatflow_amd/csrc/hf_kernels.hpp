@@ -959,29 +959,48 @@ struct ProjVecs { const double* V[PROJ_MT]; int slot[PROJ_MT]; int m; };
 // partial sums of h_k = V_k . f and (Fnew != null) of the Gram column g_k = V_k . Fnew, one pass over all vectors
 __global__ __launch_bounds__(TPB) void k_proj_dots(int n, ProjVecs a, const double* __restrict__ f, const double* __restrict__ Fnew,
                                                    double* __restrict__ part /* [2 * PROJ_MT][MAXP] */) {
-  __shared__ double s4[4];
+  __shared__ double sw[TPB / 64][2 * PROJ_MT];
   double ah[PROJ_MT], ag[PROJ_MT];
 #pragma unroll
   for (int k = 0; k < PROJ_MT; ++k) { ah[k] = 0.0; ag[k] = 0.0; }
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+  // two rows per pass: the loads of both (up to 2 m + 4) are in flight together - the stored vectors come from HBM
+  const int stride = gridDim.x * TPB;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += 2 * stride) {
+    const int i2 = i + stride;
+    const bool two = i2 < n;
     const double fi = f ? f[i] : 0.0, gi = Fnew ? Fnew[i] : 0.0;
+    const double fj = (f && two) ? f[i2] : 0.0, gj = (Fnew && two) ? Fnew[i2] : 0.0;
+    double v0[PROJ_MT], v1[PROJ_MT];
 #pragma unroll
-    for (int k = 0; k < PROJ_MT; ++k)
-      if (k < a.m) {
-        const double v = a.V[k][i];
-        ah[k] += v * fi;
-        ag[k] += v * gi;
-      }
+    for (int k = 0; k < PROJ_MT; ++k) {
+      v0[k] = k < a.m ? a.V[k][i] : 0.0;
+      v1[k] = (k < a.m && two) ? a.V[k][i2] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < PROJ_MT; ++k) {
+      ah[k] += v0[k] * fi;
+      ag[k] += v0[k] * gi;
+      ah[k] += v1[k] * fj;
+      ag[k] += v1[k] * gj;
+    }
   }
+  // all 2m sums through one barrier: shuffle tree per wavefront, then the four wave sums in wave order (block_sum's order)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < PROJ_MT; ++k)
     if (k < a.m) {
-      const double th = block_sum(ah[k], s4), tg = block_sum(ag[k], s4);
-      if (threadIdx.x == 0) {
-        part[(2 * k) * MAXP + blockIdx.x] = th;
-        part[(2 * k + 1) * MAXP + blockIdx.x] = tg;
-      }
+      double th = ah[k], tg = ag[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { th += __shfl_down(th, o, 64); tg += __shfl_down(tg, o, 64); }
+      if (lane == 0) { sw[wave][2 * k] = th; sw[wave][2 * k + 1] = tg; }
     }
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < 2 * a.m) {
+    double t = sw[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < TPB / 64; ++w) t += sw[w][threadIdx.x];
+    part[threadIdx.x * MAXP + blockIdx.x] = t;
+  }
 }
 
 // One workgroup: finish the sums (a wavefront per sum, fixed order), store the Gram column of slot `jnew` (if >= 0),
@@ -989,7 +1008,8 @@ __global__ __launch_bounds__(TPB) void k_proj_dots(int n, ProjVecs a, const doub
 // positive semi-definite, so its largest remaining entry sits on the diagonal); directions whose pivot falls below
 // 1e-12 of the first are left out (nearly dependent solutions).  alpha[slot] receives the coefficients (0 for
 // slots left out), alpha[PROJ_MT] the rank.
-__global__ __launch_bounds__(TPB) void k_proj_solve(int P, ProjVecs a, int jnew, int do_solve, double* __restrict__ part,
+constexpr int PROJ_SOLVE_T = 1024;   // 16 wavefronts: one or two partial arrays each (the sums are the long part of the kernel)
+__global__ __launch_bounds__(PROJ_SOLVE_T) void k_proj_solve(int P, ProjVecs a, int jnew, int do_solve, double* __restrict__ part,
                                                     double* __restrict__ G /* [PROJ_MT][PROJ_MT] by slot */, double* __restrict__ alpha) {
   __shared__ double sh[PROJ_MT], sg[PROJ_MT];
   __shared__ double A[PROJ_MT][PROJ_MT + 1], bb[PROJ_MT], dd[PROJ_MT], xx[PROJ_MT];
@@ -1000,7 +1020,7 @@ __global__ __launch_bounds__(TPB) void k_proj_solve(int P, ProjVecs a, int jnew,
   G += blockIdx.x * PROJ_MT * PROJ_MT;
   alpha += blockIdx.x * (PROJ_MT + 1);
   const int m = a.m, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int q = wave; q < 2 * m; q += TPB / 64) {           // sum q: partial array q of `part`
+  for (int q = wave; q < 2 * m; q += PROJ_SOLVE_T / 64) {  // sum q: partial array q of `part`
     double v = 0.0;
     for (int k0 = 0; k0 < P; k0 += 256) {
       double e[4];

@@ -560,7 +560,7 @@ void proj_column(hf_ctx* ctx, int slot, const double* f, bool solve) {
   const ProjVecs a = proj_active(ctx);
   hipLaunchKernelGGL(k_proj_dots, dim3(ctx->P), dim3(TPB), 0, ctx->stream, ctx->n, a, f, slot >= 0 ? Q.F[slot] : static_cast<const double*>(nullptr),
                      Q.part);
-  hipLaunchKernelGGL(k_proj_solve, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, a, slot, solve ? 1 : 0, Q.part, Q.G, Q.alpha);
+  hipLaunchKernelGGL(k_proj_solve, dim3(1), dim3(PROJ_SOLVE_T), 0, ctx->stream, ctx->P, a, slot, solve ? 1 : 0, Q.part, Q.G, Q.alpha);
 }
 
 // w = R d for a new boundary direction d:  A_hat w = -lift(d) on the free rows, w_B = d  (one extra solve).
