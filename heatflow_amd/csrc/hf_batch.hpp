@@ -448,12 +448,21 @@ __global__ __launch_bounds__(TPB) void kb_proj_combine(int n, ProjVecs a, const 
   double c[PROJ_MH];
 #pragma unroll
   for (int k = 0; k < PROJ_MH; ++k) c[k] = k < a.m ? alpha[j * (PROJ_MT + 1) + a.slot[k]] : 0.0;
-  for (size_t q = static_cast<size_t>(blockIdx.x) * TPB + threadIdx.x; q < static_cast<size_t>(n) * NV; q += static_cast<size_t>(gridDim.x) * TPB) {
-    double s = 0.0;                          // TPB is a multiple of NV: a thread stays with its column
+  const size_t total = static_cast<size_t>(n) * NV, stride = static_cast<size_t>(gridDim.x) * TPB;
+  for (size_t q = static_cast<size_t>(blockIdx.x) * TPB + threadIdx.x; q < total; q += 2 * stride) {   // two entries per pass
+    const size_t q2 = q + stride;            // TPB is a multiple of NV: a thread stays with its column
+    const bool two = q2 < total;
+    double v0[PROJ_MH], v1[PROJ_MH];
 #pragma unroll
-    for (int k = 0; k < PROJ_MH; ++k)
-      if (k < a.m) s += c[k] * a.V[k][q];
-    u[q] = s;
+    for (int k = 0; k < PROJ_MH; ++k) {
+      v0[k] = k < a.m ? a.V[k][q] : 0.0;
+      v1[k] = (k < a.m && two) ? a.V[k][q2] : 0.0;
+    }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < PROJ_MH; ++k) { s0 += c[k] * v0[k]; s1 += c[k] * v1[k]; }
+    u[q] = s0;
+    if (two) u[q2] = s1;
   }
 }
 

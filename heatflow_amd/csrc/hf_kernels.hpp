@@ -1105,12 +1105,21 @@ __global__ __launch_bounds__(TPB) void k_proj_combine(int n, ProjVecs a, const d
   double c[PROJ_MT];
 #pragma unroll
   for (int k = 0; k < PROJ_MT; ++k) c[k] = k < a.m ? alpha[a.slot[k]] : 0.0;
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-    double s = 0.0;
+  const int stride = gridDim.x * TPB;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += 2 * stride) {      // two rows per pass, as k_proj_dots
+    const int i2 = i + stride;
+    const bool two = i2 < n;
+    double v0[PROJ_MT], v1[PROJ_MT];
 #pragma unroll
-    for (int k = 0; k < PROJ_MT; ++k)
-      if (k < a.m) s += c[k] * a.V[k][i];
-    u[i] = s;
+    for (int k = 0; k < PROJ_MT; ++k) {
+      v0[k] = k < a.m ? a.V[k][i] : 0.0;
+      v1[k] = (k < a.m && two) ? a.V[k][i2] : 0.0;
+    }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < PROJ_MT; ++k) { s0 += c[k] * v0[k]; s1 += c[k] * v1[k]; }
+    u[i] = s0;
+    if (two) u[i2] = s1;
   }
 }
 
