@@ -29,6 +29,9 @@ constexpr int RB = 256;        // rows per chunk of the vector kernels
 constexpr int RBA = HF_RBA;    // CSR rows owned by one assembly workgroup (= its thread count); 512 measured 7 % slower
 constexpr int TPB = 256;       // threads per workgroup = 4 wavefronts of 64
 constexpr int NCOL = 32;       // max colours per row block (uint32 mask)
+#ifndef HF_STAGE_U
+#define HF_STAGE_U 2   // column-list entries per lane and pass while a chunk's operand slice is staged (k_spmv, C16)
+#endif
 #ifndef HF_UNROLL
 #define HF_UNROLL 4
 #endif

@@ -683,10 +683,22 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
         v[u] = in ? static_cast<double>(vals[k + u * TS]) : 0.0;
         id[u] = in ? static_cast<int>(comp.id[k + u * TS]) : 0;
       }
-      for (int i = threadIdx.x; i < nd; i += TS) {
-        const int c = comp.dict[d0 + i];
-        xd[i] = x[c];
-        if ((MODE == 4 || MODE == 8 || MODE == 9) && c == r0) s_own = i;
+      // HF_STAGE_U entries of the column list per lane and pass (the fine operator's lists hold 1.3 TS entries, those of the
+      // transfer operators up to 3.5 TS): the list loads go out together and the gathers after them - dependent round
+      // trips per chunk: two instead of two per TS entries
+      for (int i = threadIdx.x; i < nd; i += HF_STAGE_U * TS) {
+        int c[HF_STAGE_U];
+        double xv[HF_STAGE_U];
+#pragma unroll
+        for (int u = 0; u < HF_STAGE_U; ++u) c[u] = (i + u * TS < nd) ? comp.dict[d0 + i + u * TS] : 0;
+#pragma unroll
+        for (int u = 0; u < HF_STAGE_U; ++u) xv[u] = (i + u * TS < nd) ? x[c[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < HF_STAGE_U; ++u)
+          if (i + u * TS < nd) {
+            xd[i + u * TS] = xv[u];
+            if ((MODE == 4 || MODE == 8 || MODE == 9) && c[u] == r0) s_own = i + u * TS;
+          }
       }
       __syncthreads();
       if ((MODE == 4 || MODE == 8 || MODE == 9) && comp.own && pin) e_x = xd[s_own + (prow - r0)];
