@@ -255,3 +255,35 @@ def test_c5_sixty_four_point_kappa_sweep_on_one_gpu(hip, tmp_path):
     assert finals[0] < finals[1] < finals[2]                      # a better conductor heats the far side more
     print(f"64 points x {len(coords)} DOF x 100 steps in {timing['points_s']:.2f} s of point loop "
           f"({64 * len(coords) * 100 / timing['points_s']:.3e} DOF-updates/s)")
+
+
+def test_bench_line_keeps_its_contract_on_a_small_mesh(hip):
+    """bench.py end to end on a coarse mesh (seconds): exactly one JSON line with the driver's keys, value consistent with
+    ms_per_step, a roofline object for the dominant kernel with live in-loop timing, and a cpu_baseline from the oracle."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "3.0", "--steps", "8", "--warmup", "5", "--cpu-steps", "3",
+           "--jacobi-steps", "2", "--sweep-points", "0", "--hbm-scale", "0", "--cpu-farm-points", "0", "--device-warmup-s", "0",
+           "--profile-steps", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 8 and out["warmup"] == 5 and out["dtype"] == "f64" and out["vs_baseline"] is None
+    n = out["config"]["n_dof"]
+    assert abs(out["value"] - n * 8 / (out["ms_per_step"] * 8e-3)) <= 1e-6 * out["value"]
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["us_per_launch"] > 0 and "in-loop" in r["timing"] and r["assembly"]["default_mode"] == "row_gather"
+    assert r["jacobi_pcg_iteration"]["bytes"] == 12 * out["config"]["nnz"] + 84 * n
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == out["unit"]
+    assert out["config"]["gpu_over_cpu"] == pytest.approx(out["value"] / c["value"])
