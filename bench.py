@@ -57,7 +57,7 @@ MESH_SCALE = 0.43          # all `mesh:` values x 0.43 -> 1.04 M nodes (within +
 HBM_SCALE = 0.1075         # -> 16 M nodes: matrix 1.3 GB, vectors 128 MB each, nothing stays in the 256 MiB Infinity Cache
 SWEEP_POINTS = 64          # BASELINE C5
 SWEEP_BATCH = 8            # points per batched time loop (hf_batch_*): columns of one multi-vector PCG
-SWEEP_CONCURRENT = 2       # time loops in flight per rank (64 points on one GPU in batches of 8: 1/2/4 in flight = 5.8/6.9/5.6-6.5e8 DOF-updates/s; unbatched, 6 in flight: 4.5e8)
+SWEEP_CONCURRENT = 2       # time loops in flight per rank (64 points on one GPU in batches of 8: 1 / 2 in flight = 7.1 / 9.0e8 DOF-updates/s; unbatched, 6 in flight: 4.5e8)
 
 
 def parse_args(argv=None):
