@@ -34,13 +34,13 @@ int lanes_for(const amg::Csr& m) {
 // f32: values stored in single precision (operators that only act inside the preconditioner).  Operators big enough
 // for the LDS-staged kernel also get its compressed column stream (a sorted column list per chunk + a 16-bit position
 // per nonzero): 6 instead of 12 bytes per nonzero together.
-int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d, bool f32 = false) {
+int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d, bool f32 = false, bool stream = true /* false: never run by the LDS-staged kernel, skip its tables */) {
   d.nrow = h.nrow; d.ncol = h.ncol; d.nnz = h.nnz(); d.lanes = lanes_for(h);
   for (int i = 0; i < h.nrow; ++i) d.max_row = std::max(d.max_row, h.ptr[i + 1] - h.ptr[i]);
   d.rpc = 0;
   static const int min_rows = std::getenv("HEATFLOW_STREAM_MIN_ROWS") ? std::atoi(std::getenv("HEATFLOW_STREAM_MIN_ROWS")) : 100000;
   static const int max_nnz = std::getenv("HEATFLOW_STREAM_NNZ") ? std::atoi(std::getenv("HEATFLOW_STREAM_NNZ")) : 4096;
-  if (h.nrow >= min_rows) {  // enough 512-row chunks to fill the chip: LDS-staged kernel, chunk products within 64 KB
+  if (stream && h.nrow >= min_rows) {  // enough 512-row chunks to fill the chip: LDS-staged kernel, chunk products within 64 KB
     for (int rpc = TS; rpc >= 32; rpc /= 2) {
       int mx = 0;
       for (int r0 = 0; r0 < h.nrow; r0 += rpc) mx = std::max(mx, h.ptr[std::min(h.nrow, r0 + rpc)] - h.ptr[r0]);
@@ -152,7 +152,11 @@ int build_amg(hf_ctx* ctx) {
         L.res = ctx->amg[l - 1].cat + ctx->amg[l - 1].n;
       }
     }
-    if (l + 1 < nl) { HF_TRY(upload_csr(ctx, hl.P, L.P, f32)); HF_TRY(upload_csr(ctx, hl.R, L.R, f32)); }
+    if (l + 1 < nl) {
+      HF_TRY(upload_csr(ctx, hl.P, L.P, f32));
+      // with a fused down leg the single-column cycle never applies R_0 itself (the batched loop does, through kb_csr)
+      HF_TRY(upload_csr(ctx, hl.R, L.R, f32, !(l == 0 && L.Rt.nrow > 0)));
+    }
   }
   if (std::getenv("HEATFLOW_DEBUG")) {
     auto show = [](const char* nm, size_t l, const DevCsr& m) {
