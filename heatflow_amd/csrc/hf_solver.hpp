@@ -289,10 +289,12 @@ void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
   else launch_vec_t<VMODE, double>(c, m, m.val, x, y);
 }
 
-// z = B r: one V(1,1) cycle.  Fixed buffer roles (no pointer swaps): on entry d_z holds w0 D^-1 r (written by the update / start kernel); on exit
-// d_z2 holds z and part_rz[out_slot] the partials of r.z.  The finest level runs its two sweeps explicitly
-// (its operator changes with every re-assembly); every intermediate level is two launches, the fused
-// down leg Rt and the fused up leg GP (amg_host.hpp), the coarsest level a dense mat-vec.
+// z = B r: one V(1,1) cycle.  Fixed buffer roles (no pointer swaps): on entry d_z holds w0 D^-1 r (written by the update /
+// start kernel; not needed when both legs of the finest level are fused); on exit d_z2 holds z and part_rz[out_slot] the
+// partials of r.z.  The finest level comes in three forms (build_amg chooses by size, HEATFLOW_AMG_FUSE0): explicit
+// residual + R_0 down and P_0 + sweep up, fused down leg Rt_0 with the explicit up leg, or both legs fused; every
+// intermediate level is two launches, the fused down leg Rt and the fused up leg GP (amg_host.hpp), the coarsest level
+// a dense mat-vec.  With `test_convergence` the first kernel of the cycle tests the iterate the cycle starts from.
 void vcycle(hf_ctx* c, int out_slot, bool test_convergence = false) {
   const int nl = static_cast<int>(c->amg.size());
   DevLevel& L0 = c->amg[0];

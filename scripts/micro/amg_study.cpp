@@ -34,7 +34,7 @@ static int nc = 0;
 static int smoother = 0, nu = 1;
 static double over = 1.0;
 
-static int smoother_c = -1, nu_c = -1, nu_l1 = -1, nu_l2 = -1, gamma_c = 1;
+static int smoother_c = -1, nu_c = -1, nu_l1 = -1, nu_l2 = -1, gamma_c = 1, gamma_from = 0;
 static void smooth(const Lev& l, const Vec& b, Vec& x, bool zero_guess) {
   const int n = l.A->nrow;
   const bool fine = &l == &L[0];
@@ -88,7 +88,7 @@ static void vcycle(size_t lev, const Vec& b, Vec& x) {
   for (int i = 0; i < n; ++i) r[i] = b[i] - t[i];
   matvec(*l.R, r, bc);
   vcycle(lev + 1, bc, ec);
-  if (gamma_c > 1 && lev + 2 < L.size()) {   // W-cycle: second visit with the residual of the first
+  if (gamma_c > 1 && lev + 2 < L.size() && static_cast<int>(lev) >= gamma_from) {   // W-cycle: second visit with the residual of the first
     Vec t2, bc2(bc.size()), ec2;
     matvec(*L[lev + 1].A, ec, t2);
     for (size_t i = 0; i < bc.size(); ++i) bc2[i] = bc[i] - t2[i];
@@ -132,6 +132,7 @@ int main(int argc, char** argv) {
   if (kv.count("nul1")) nu_l1 = (int)kv["nul1"];
   if (kv.count("nul2")) nu_l2 = (int)kv["nul2"];
   if (kv.count("gamma")) gamma_c = (int)kv["gamma"];
+  if (kv.count("gfrom")) gamma_from = (int)kv["gfrom"];
   amg::Hierarchy H;
   Csr Acopy = A0;
   auto t0 = std::chrono::steady_clock::now();
