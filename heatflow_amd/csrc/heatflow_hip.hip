@@ -506,6 +506,7 @@ int hf_assemble(hf_ctx* ctx, double dt, int32_t mode) {
   HF_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->last_ms = ms;
   if (ctx->precond == 1 && !(ctx->amg_ready && ctx->amg_reuse)) HF_TRY(build_amg(ctx));
+  else if (ctx->precond == 1) ctx->amg_fine_stale = true;      // hierarchy kept (reuse): its fused fine-level operators hold the old A
   if (ctx->precond == 1 && ctx->amg_ready) {  // level 0 aliases the fine operator: refresh its pointers
     ctx->amg[0].A.val = ctx->d_A;
     ctx->amg[0].dinv = ctx->d_dinv;

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(TPB) void kb_begin(int P, double rtol, double atol,
   double rz0 = 0.0;
   if (part_rz0 != nullptr) rz0 = col_partials<NV>(part_rz0 + j * MAXP, P, sw);
   if (threadIdx.x < NV) {
-    const double tol = fmax(rtol * sqrt(bn2), atol);
+    const double tol = fmax(rtol * sqrt(bn2 > 0.0 ? bn2 : zz), atol);   // zero right-hand side: relative to the start residual (k_pcg_begin)
     Scal* sc = scal + j;
     sc->tol2 = tol * tol;
     sc->bn2 = bn2;

@@ -184,6 +184,7 @@ struct hf_ctx {
   double* d_coarse_inv = nullptr;
   float* d_coarse_inv_f = nullptr;   // the same in single precision (amg_f32)
   int coarse_n = 0, coarse_ld = 0;   // dense inverse, row-major, leading dimension a multiple of 4 (16-byte row loads)
+  bool amg_fine_stale = false;       // frozen hierarchy (reuse) and the fine operator re-valued since it was built: the fused down leg Rt_0 no longer matches A
   int amg_fuse0 = 0;                 // finest level of the V-cycle: 0 explicit sweeps, 1 fused legs Rt_0 / GP_0, 2 fused down leg only (chosen by size in build_amg; HEATFLOW_AMG_FUSE0 overrides)
   bool amg_f32 = true;               // operators of the preconditioner below the fine level stored in float (HEATFLOW_AMG_F32=0: double)
   double amg_opc = 0.0, amg_setup_s = 0.0;

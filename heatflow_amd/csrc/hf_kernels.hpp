@@ -818,7 +818,9 @@ __global__ __launch_bounds__(TPB) void k_pcg_begin(int P, double rtol, double at
   const double zz = sum_partials(part_zz, P, s4);
   const double bn2 = sum_partials(part_bn, P, s4);
   if (threadIdx.x == 0) {
-    const double tol = fmax(rtol * sqrt(bn2), atol);
+    // relative to the right-hand side; a zero right-hand side (the exact answer is then zero) with a non-zero start vector
+    // - a warm-started projection of a field that has gone flat - is measured against the start residual instead
+    const double tol = fmax(rtol * sqrt(bn2 > 0.0 ? bn2 : zz), atol);
     scal->tol2 = tol * tol;
     scal->bn2 = bn2;
     scal->zz = zz;

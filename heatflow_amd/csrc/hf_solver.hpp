@@ -154,8 +154,9 @@ int build_amg(hf_ctx* ctx) {
     }
     if (l + 1 < nl) {
       HF_TRY(upload_csr(ctx, hl.P, L.P, f32));
-      // with a fused down leg the single-column cycle never applies R_0 itself (the batched loop does, through kb_csr)
-      HF_TRY(upload_csr(ctx, hl.R, L.R, f32, !(l == 0 && L.Rt.nrow > 0)));
+      // with a fused down leg the single-column cycle applies R_0 itself only after the fine operator has been re-valued
+      // under a frozen hierarchy (vcycle); the batched loop always does, through kb_csr, which needs no stream tables
+      HF_TRY(upload_csr(ctx, hl.R, L.R, f32, !(l == 0 && L.Rt.nrow > 0) || ctx->amg_reuse != 0));
     }
   }
   if (std::getenv("HEATFLOW_DEBUG")) {
@@ -212,6 +213,7 @@ int build_amg(hf_ctx* ctx) {
   }
   lap("+ dense inverse");
   ctx->amg_opc = H.op_complexity;
+  ctx->amg_fine_stale = false;
   ctx->amg_ready = true;
   ctx->amg_setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return HF_OK;
@@ -303,7 +305,10 @@ void vcycle(hf_ctx* c, int out_slot, bool test_convergence = false) {
     return;
   }
   const bool fused0 = L0.GP.nrow > 0;     // both legs of the finest level fused
-  if (L0.Rt.nrow > 0) {
+  // A fused down leg alone must match the operator the explicit up leg sweeps over: after a re-valuation under a frozen
+  // hierarchy it does not (Rt_0 holds the old A), the cycle would no longer be symmetric and PCG breaks down - the
+  // explicit down leg takes over.  With both legs fused the cycle is a fixed SPD operator of the old A: weaker, but sound.
+  if (L0.Rt.nrow > 0 && (fused0 || !c->amg_fine_stale)) {
     // finest level through its fused legs: b_1 = Rt_0 r (pre-smoothing from zero, residual and restriction in one
     // operator; early exit if the update before it has converged)
     launch_stream<0>(c, L0.Rt, c->d_r, c->amg[1].b, nullptr, nullptr, test_convergence ? c->d_part_zz : nullptr);

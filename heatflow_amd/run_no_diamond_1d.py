@@ -243,10 +243,10 @@ def run_1d(cfg, mesh_folder_2d, mesh_folder_1d=None, rebuild_mesh=False, visuali
         if watcher_points is not None:
             write_watcher_csv(os.path.join(save_folder, "watcher_points.csv"), times, wnames,
                               {nm: samples[:, k] for k, nm in enumerate(wnames)})
-        print("\\n--- Timing Summary ---")
+        print("\n--- Timing Summary ---")
         print(f"Total time: {time.time() - t_start:.2f} s")
         print(f"Loop time: {loop_time:.2f} s")
         print(f"Average time per step: {loop_time / max(num_steps, 1):.4f} s")
-        print("----------------------\\n")
+        print("----------------------\n")
         return {"z": z, "cell_tags": cell_tags, "nodes_2d": nodes_2d, "times": np.array(times), "u": u,
                 "watchers": {nm: samples[:, k] for k, nm in enumerate(wnames)}, "save_folder": save_folder}

@@ -163,7 +163,8 @@ int hf_sample(hf_ctx* ctx, int32_t n_s, const int32_t* nodes, double* out);
 
 /* One backward-Euler step: b = M u^n - A[:,B] g, b_B = g, solve A_hat u^{n+1} = b by
  * Jacobi-PCG started from u^n (with u_B = g), in place.  Stops when
- * ||D^-1 r||_2 <= max(rtol * ||D^-1 b||_2, atol).  iters / resid (relative) may be NULL. */
+ * ||D^-1 r||_2 <= max(rtol * ||D^-1 b||_2, atol)  (a zero right-hand side - the answer is then zero - is measured
+ * against the start residual instead).  iters / resid (relative) may be NULL. */
 int hf_step(hf_ctx* ctx, const double* g_bc, double rtol, double atol, int32_t max_it, int32_t* iters, double* resid);
 
 /* n_steps steps in one call: g_bc_all = n_steps x n_bc; after every step the n_s nodes

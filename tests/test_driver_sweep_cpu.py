@@ -369,3 +369,27 @@ def test_batched_sweeps_give_the_same_rows_and_files_as_point_by_point(tmp_path)
         wa = np.genfromtxt(os.path.join(a["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
         wb = np.genfromtxt(os.path.join(b["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
         assert np.abs(wa["oside"] - wb["oside"]).max() < 1e-9
+
+
+def test_root_level_modules_keep_the_reference_names():
+    """A user of the reference imports `parameter_sweep`, `run_with_diamond`, `run_no_diamond`, `run_no_diamond_1d` from the
+    repository root (parameter_sweep.py:43, with_diamond.py:1, no_diamond.py:1, no_diamond_1d.py:1): the same names resolve
+    here, and the experiment scripts exist beside them."""
+    import importlib
+    import os
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    try:
+        for name, attrs in (("parameter_sweep", ("run_parameter_sweep", "run_single_simulation", "create_parameter_grid", "main")),
+                            ("run_with_diamond", ("run_simulation",)), ("run_no_diamond", ("run_simulation",)),
+                            ("run_no_diamond_1d", ("run_1d",))):
+            mod = importlib.import_module(name)
+            for a in attrs:
+                assert hasattr(mod, a), (name, a)
+    finally:
+        sys.path.remove(ROOT)
+    for script in ("with_diamond.py", "no_diamond.py", "no_diamond_1d.py", "sweep_test.py", "parameter_sweep.py"):
+        assert os.path.isfile(os.path.join(ROOT, script)), script

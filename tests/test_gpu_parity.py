@@ -273,10 +273,17 @@ def test_multigrid_loop_reports_non_convergence_and_recovers(hip, case_with_diam
         prob.close()
 
 
-def test_amg_cuts_iterations_and_frozen_hierarchy_survives_a_kappa_change(hip, case_with_diamond_small):
+@pytest.mark.parametrize("fine_level", ["default", "0", "1", "2"])
+def test_amg_cuts_iterations_and_frozen_hierarchy_survives_a_kappa_change(hip, case_with_diamond_small, fine_level, monkeypatch):
     """Same answer with ~10x fewer iterations; with reuse=True a kappa change re-values only the
-    fine operator (coarse levels frozen) and the result still matches the oracle."""
+    fine operator (coarse levels frozen) and the result still matches the oracle.  Every form of the finest level
+    (HEATFLOW_AMG_FUSE0, with the LDS-staged kernel admitted on this small mesh so that the fused legs really run): a
+    fused down leg alone holds the operator it was built from and must hand over to the explicit one after the
+    re-valuation, or the cycle loses its symmetry and PCG breaks down."""
     import copy
+    if fine_level != "default":
+        monkeypatch.setenv("HEATFLOW_STREAM_MIN_ROWS", "1000")
+        monkeypatch.setenv("HEATFLOW_AMG_FUSE0", fine_level)
     cfg, stack, mesh = case_with_diamond_small
     pj = make_problem(cfg, stack, mesh, precond=0)
     pa = make_problem(cfg, stack, mesh, precond=1, amg_reuse=True)
@@ -300,12 +307,40 @@ def test_amg_cuts_iterations_and_frozen_hierarchy_survives_a_kappa_change(hip, c
         ref = oracle_run(cfg2, mesh, 10)
         for bc in pa.bcs:
             bc.update(0.0)
+        n_before = len(pa.iters)
         for k in range(10):
             pa.step((k + 1) * pa.dt)
         assert np.max(np.abs(pa.state() - ref["fields"][-1])) <= FIELD_TOL_K
+        assert max(pa.iters[n_before:]) <= 3 * max(pa.iters[:n_before]) + 5     # still a preconditioner, not a fallback crawl
+        assert pa.backend.amg_info()["jacobi_fallbacks"] == 0
     finally:
         pj.close()
         pa.close()
+
+
+def test_flux_projection_of_a_field_gone_flat_after_a_warm_start(hip, case_no_diamond_small):
+    """Second simulation on one context (a sweep re-uses it): the state is reset to the uniform initial temperature, so
+    grad T = 0 and the projection's right-hand side is exactly zero, while its warm start still holds the last gradient
+    of the previous simulation.  The solve must return (numerically) zero - the stopping rule falls back to the start
+    residual when ||b|| = 0 - and not run to max_it (the failure every point after the first of a no-diamond sweep
+    showed: 'PCG not converged in 5000 iterations')."""
+    cfg, stack, mesh = case_no_diamond_small
+    prob = make_problem(cfg, stack, mesh)
+    try:
+        prob.backend.flux_setup()
+        prob.run(8, time_varying=[prob.bcs[3]])
+        for comps, kw in ((2, dict(want_z=False)), (3, dict())):
+            it = prob.backend.flux_solve(prob.rtol, 5000, **kw)
+            g_hot = prob.backend.flux_sample(np.arange(0, prob.n, 7, dtype=np.int32), **kw)[1]
+            assert np.abs(g_hot).max() > 1e3 and max(np.atleast_1d(it)) >= 3          # a real gradient is in the warm start
+            prob.set_state(300.0)
+            it0 = prob.backend.flux_solve(prob.rtol, 5000, **kw)                       # b = 0 exactly
+            g_flat = prob.backend.flux_sample(np.arange(0, prob.n, 7, dtype=np.int32), **kw)[1]
+            assert max(np.atleast_1d(it0)) < 200
+            assert np.abs(g_flat).max() <= 1e-8 * np.abs(g_hot).max()
+            prob.run(8, time_varying=[prob.bcs[3]])                                      # heat up again for the next variant
+    finally:
+        prob.close()
 
 
 def test_read_flux_projection_matches_oracle(hip, case_no_diamond_small):
@@ -420,6 +455,36 @@ def test_kappa_sweep_on_gpu_reuses_mesh_and_hierarchy(hip, tmp_path):
         assert np.abs(got["oside"] - ref["watchers"][:, 1]).max() <= FIELD_TOL_K
         assert np.abs(got["pside"] - ref["watchers"][:, 0]).max() <= FIELD_TOL_K
     assert os.path.isfile(os.path.join(out, "rmse_summary.csv"))
+
+
+def test_no_diamond_grid_sweep_every_point_succeeds_on_one_context(hip, tmp_path):
+    """parameter_sweep.run_parameter_sweep on the no-diamond read-flux configuration (the reference's production sweep,
+    parameter_sweep.py:289-536): fwhm x k grid on one mesh, every point after the first re-uses the solver context - and
+    with it the warm start of the flux projection, which meets a zero right-hand side in the new run's first steps."""
+    import csv
+    import os
+    import yaml
+
+    from conftest import HEATING_CSV, load_cfg
+    from heatflow_amd import parameter_sweep as ps
+    from heatflow_amd.geometry import scale_mesh_sizes
+
+    cfg = scale_mesh_sizes(load_cfg("geballe_no_diamond_read_flux"), 3.0)
+    cfg["heating"]["file"] = HEATING_CSV
+    cfg["timing"]["num_steps"] = 12
+    cfg["timing"]["t_final"] = 12 * 1.875e-7
+    cfg_path = str(tmp_path / "cfg.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    out = str(tmp_path / "out")
+    ps.run_parameter_sweep(cfg_path, out, (1.0e-5, 1.4e-5), (3.4, 4.2), (1.9e-6, 1.9e-6), (2, 3, 1),
+                           base_mesh_folder=str(tmp_path / "meshes"))
+    with open(os.path.join(out, "successful_runs.csv")) as f:
+        rows = list(csv.DictReader(f))
+    failed = os.path.join(out, "failed_runs.csv")
+    assert len(rows) == 6, open(failed).read() if os.path.isfile(failed) else rows
+    for r in rows:
+        assert r["status"] == "success" and os.path.isfile(os.path.join(r["output_dir"], "radial_gradient.csv"))
 
 
 def _unit_square_mesh(nz, nr):
