@@ -1186,6 +1186,30 @@ def test_batched_time_loop_with_a_shared_operator_matches_single_runs(hip, preco
         prob.close()
 
 
+@pytest.mark.parametrize("precond", [0, 1])
+def test_batched_loop_reports_non_convergence_and_the_context_recovers(hip, precond, case_with_diamond_small):
+    """hf_batch_run with too few iterations allowed: NotConverged (polled multigrid loop and burst loop alike); after
+    hf_batch_end the same context runs a normal single-column loop."""
+    cfg, stack, mesh = case_with_diamond_small
+    prob = make_problem(cfg, stack, mesh, precond=precond, amg_reuse=True)
+    be = prob.backend
+    try:
+        for bc in prob.bcs:
+            bc.update(0.0)
+        g = np.array([prob.bc_values((k + 1) * prob.dt, [prob.bcs[3]]) for k in range(8)])
+        be.batch_begin(4, per_column_operator=hip.BATCH_SHARED)
+        for j in range(4):
+            be.batch_set_state(j, np.full(prob.n, 300.0))
+        with pytest.raises(hip.NotConverged, match="not converged|breakdown"):
+            be.batch_run(np.repeat(g[:, :, None], 4, axis=2), prob.rtol, 0.0, 2, None)
+        be.batch_end()
+        prob.set_state(300.0)
+        _, _, iters = prob.run(8, time_varying=[prob.bcs[3]])
+        assert np.asarray(iters).max() >= 3 and np.isfinite(prob.state()).all()
+    finally:
+        prob.close()
+
+
 def test_batch_call_order_and_argument_errors(hip, case_with_diamond_small):
     """hf_batch_*: wrong order / bad arguments are refused with a message, the context stays usable, and a batch is
     closed by anything that invalidates what it was sized for."""
