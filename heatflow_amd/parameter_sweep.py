@@ -76,6 +76,19 @@ def _dist():
     return None
 
 
+def local_device():
+    """GPU of this rank: LOCAL_RANK, wrapped onto the GPUs that exist when a rehearsal (HEATFLOW_SWEEP_BACKEND=gloo)
+    runs more ranks than the box has devices."""
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HEATFLOW_SWEEP_BACKEND") == "gloo":
+        try:
+            import torch
+            return lr % max(torch.cuda.device_count(), 1)
+        except ImportError:
+            return 0
+    return lr
+
+
 def world_info():
     d = _dist()
     return (d.get_rank(), d.get_world_size()) if d is not None else (0, 1)
@@ -240,7 +253,7 @@ def run_parameter_sweep(base_config_path, output_dir, fwhm_range, k_range, width
         base_config = yaml.safe_load(f)
     combos, fwhm_vals, k_vals, width_vals = create_parameter_grid(fwhm_range, k_range, width_range, num_points)
     if device_id is None:
-        device_id = int(os.environ.get("LOCAL_RANK", "0"))
+        device_id = local_device()
 
     if rank == 0:
         os.makedirs(output_dir, exist_ok=True)
@@ -347,7 +360,7 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
 
     rank, world = world_info()
     if device_id is None:
-        device_id = int(os.environ.get("LOCAL_RANK", "0"))
+        device_id = local_device()
     stack = build_stack(cfg)
     t_phase = time.perf_counter()
     arrays, tag_map = _EMPTY_MESH, None
@@ -498,7 +511,8 @@ def main(argv=None):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch
         import torch.distributed as dist
-        use_gpu = torch.cuda.is_available()
+        # HEATFLOW_SWEEP_BACKEND=gloo: rehearsal with more ranks than GPUs (ranks share devices, the mesh travels on the host)
+        use_gpu = torch.cuda.is_available() and os.environ.get("HEATFLOW_SWEEP_BACKEND") != "gloo"
         if use_gpu:
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl" if use_gpu else "gloo")
