@@ -26,7 +26,7 @@ for j in range(nv):
 stacks = [build_stack(c) for c in cfgs]
 t0 = time.time(); r1 = sess.run(cfgs[0], stacks[0], watcher_points(cfgs[0])); t_single = time.time() - t0
 t0 = time.time(); r1 = sess.run(cfgs[-1], stacks[-1], watcher_points(cfgs[-1])); t_single2 = time.time() - t0
-print(f"n = {len(mesh.coords)}  single run: first {t_single:.3f} s (set-up included), second {t_single2:.3f} s, loop {r1['loop_time']:.3f} s, "
+print(f"n = {len(mesh.coords)}  nnz = {sess.problem.backend.nnz}  single run: first {t_single:.3f} s (set-up included), second {t_single2:.3f} s, loop {r1['loop_time']:.3f} s, "
       f"gpu {sess.problem.backend.last_gpu_ms():.1f} ms, iters/step {np.mean(r1['iters']):.1f}")
 for rep in range(2):
     t0 = time.time(); res = sess.run_batch(cfgs, stacks, watcher_points(cfgs[0])); t_b = time.time() - t0
