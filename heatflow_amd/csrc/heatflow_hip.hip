@@ -42,6 +42,7 @@ inline size_t pad16(size_t b) { return (b + 15) & ~static_cast<size_t>(15); }
 int install_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int32_t* tri, const int32_t* tag, MeshTables& T) {
   free_batch(ctx);
   free_batch_state(ctx->fluxb);
+  free_batch_cols(ctx);
   proj_free(ctx);
   ctx->n = n; ctx->ne = ne; ctx->nnz = static_cast<int64_t>(T.colidx.size());
   ctx->nchunks = (n + RB - 1) / RB;
@@ -295,6 +296,84 @@ int upload_rg_tables(hf_ctx* ctx, const std::vector<double>& by_tag_k, const std
   if (by_tag_c) HF_HIP(copy_sync(ctx, ctx->d_rhoc_rg, c.data(), sizeof(double) * 64, hipMemcpyHostToDevice));
   return HF_OK;
 }
+// nv-column Jacobi-PCG state of the batched loop's read-flux projection (one gradient component of every column per solve,
+// on the unit-coefficient mass matrix of hf_flux_setup); `uprev` keeps the z component's last projection when both are asked for
+int ensure_batch_flux(hf_ctx* ctx, int nv, int ncomp) {
+  hf_ctx::Batch& F = ctx->fluxnb;
+  if (F.nv == nv && (ncomp < 2 || F.uprev != nullptr)) return HF_OK;
+  free_batch_state(F);
+  const size_t vec = static_cast<size_t>(ctx->n) * nv;
+  for (double** v : {&F.u, &F.b, &F.r, &F.p, &F.Ap, &F.z}) {
+    HF_TRY(dev_alloc(ctx, v, vec));
+    HF_HIP(hipMemsetAsync(*v, 0, sizeof(double) * vec, ctx->stream));
+  }
+  if (ncomp == 2) {
+    HF_TRY(dev_alloc(ctx, &F.uprev, vec));
+    HF_HIP(hipMemsetAsync(F.uprev, 0, sizeof(double) * vec, ctx->stream));
+  }
+  HF_TRY(dev_alloc(ctx, &F.part_pAp, static_cast<size_t>(nv) * MAXP));
+  HF_TRY(dev_alloc(ctx, &F.part_rz, 2 * static_cast<size_t>(nv) * MAXP));
+  HF_TRY(dev_alloc(ctx, &F.part_zz, static_cast<size_t>(nv) * MAXP));
+  HF_TRY(dev_alloc(ctx, &F.part_bn, static_cast<size_t>(nv) * MAXP));
+  HF_TRY(dev_alloc(ctx, &F.scal, nv));
+  HF_TRY(dev_alloc(ctx, &F.red, 1));
+  HF_HIP(hipMemsetAsync(F.scal, 0, sizeof(Scal) * nv, ctx->stream));
+  HF_HIP(hipMemsetAsync(F.red, 0, sizeof(BRed), ctx->stream));
+  if (hipHostMalloc(reinterpret_cast<void**>(&F.h_scal), sizeof(Scal) * nv) != hipSuccess) return fail(ctx, HF_ERR_ALLOC, "hipHostMalloc failed");
+  const int rpb = TPB / nv;
+  F.Pb = static_cast<int>(std::min<size_t>((static_cast<size_t>(ctx->n) + rpb - 1) / rpb, MAXP));
+  if (F.Pb >= 64) F.Pb &= ~7;
+  F.opk = 0; F.pred_iters = 0;
+  F.sysA = ctx->d_M1; F.sysDinv = ctx->d_dinv1;
+  F.lds = ctx->bcols.nv == nv;        // same mesh, same nv: the main batch's staged SpMV serves the projection too
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  F.nv = nv;
+  return HF_OK;
+}
+
+// After a batched step: per wanted component, the gradient right-hand sides of all columns (k_grad_rows on column j of the
+// interleaved state), one nv-column Jacobi-PCG warm-started from that component's last projection, and the samples
+// out[component][column][node] (reference run_no_diamond.py:543-566, once per run and step).
+int batch_flux_step(hf_ctx* ctx, int components, double rtol, int max_it, int nfs, double* out, int32_t* it_out) {
+  hf_ctx::Batch& B = ctx->batch;
+  hf_ctx::Batch& F = ctx->fluxnb;
+  const int nv = B.nv;
+  const int capd = ctx->rg_max_dict;
+  const size_t sm = static_cast<size_t>(capd) * 16 + static_cast<size_t>(capd + (capd & 1)) * 8 + (RBA + 4) * 4 +
+                    (static_cast<size_t>((ctx->max_blk_nnz + 1) & ~1) / 8 + 3) * 16;
+  const int grid = std::min(ctx->nblk_a, 2048);
+  int done = 0;
+  for (int comp = 0; comp < 2; ++comp) {
+    if (!((components >> comp) & 1)) continue;
+    const bool second = done == 1;                     // the r component after the z component: its own warm start
+    if (second) std::swap(F.u, F.uprev);
+    for (int j = 0; j < nv; ++j)
+      hipLaunchKernelGGL(k_grad_rows, dim3(grid), dim3(RBA), sm, ctx->stream, ctx->nblk_a, capd, ctx->d_rg_hdr,
+                         reinterpret_cast<const uint4*>(ctx->d_rg_ell), reinterpret_cast<const uint4*>(ctx->d_rg_cid), ctx->d_rg_zrb,
+                         ctx->d_rg_dict, ctx->d_rowptr, B.u, comp == 0 ? F.b + j : static_cast<double*>(nullptr),
+                         comp == 1 ? F.b + j : static_cast<double*>(nullptr), nv, nv, j);
+    HF_HIP(hipGetLastError());
+    std::swap(ctx->batch, ctx->fluxnb);
+    const int rc = batch_dispatch(ctx, [&](auto ops) { return decltype(ops)::pcg(ctx, false, rtol, 0.0, max_it); });
+    int itmax = 0;
+    for (int j = 0; j < nv; ++j) itmax = std::max(itmax, ctx->batch.h_scal[j].iters);
+    std::swap(ctx->batch, ctx->fluxnb);
+    if (it_out) it_out[done] = itmax;
+    if (rc != HF_OK) { if (second) std::swap(F.u, F.uprev); return rc; }
+    double* o = out + static_cast<size_t>(done) * nv * nfs;
+    const int thr = nfs * nv;
+    switch (nv) {
+      case 2: hipLaunchKernelGGL((kb_gather<2>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, nfs, ctx->d_fsamp_idx, F.u, o); break;
+      case 4: hipLaunchKernelGGL((kb_gather<4>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, nfs, ctx->d_fsamp_idx, F.u, o); break;
+      case 8: hipLaunchKernelGGL((kb_gather<8>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, nfs, ctx->d_fsamp_idx, F.u, o); break;
+      default: hipLaunchKernelGGL((kb_gather<16>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, nfs, ctx->d_fsamp_idx, F.u, o); break;
+    }
+    HF_HIP(hipGetLastError());
+    if (second) std::swap(F.u, F.uprev);
+    ++done;
+  }
+  return HF_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -324,7 +403,7 @@ int hf_create(int device_id, hf_ctx** out) {
   if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_mirror), sizeof(ScalMirror), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_mirror), ctx->h_mirror, 0) != hipSuccess)
     return bail(fail(ctx, HF_ERR_ALLOC, "hipHostMalloc (mapped) failed"));
-  *ctx->h_mirror = ScalMirror{0.0, 0.0, 0, 0, -1};
+  *ctx->h_mirror = ScalMirror{};               // epoch 0: no solve of this context (they count from 1) has written it
   int rc = dev_alloc(ctx, &ctx->d_scal, 1);
   if (rc == HF_OK) rc = dev_alloc(ctx, &ctx->d_part_pAp, MAXP);
   if (rc == HF_OK) rc = dev_alloc(ctx, &ctx->d_part_rz, 2 * MAXP);
@@ -345,10 +424,10 @@ int hf_destroy(hf_ctx* ctx) {
   dev_free(&ctx->d_lift_bc); dev_free(&ctx->d_lift_slot); dev_free(&ctx->d_lift_val);
   dev_free(&ctx->d_uprev); dev_free(&ctx->d_ustart);
   dev_free(&ctx->d_u); dev_free(&ctx->d_b); dev_free(&ctx->d_r); dev_free(&ctx->d_p); dev_free(&ctx->d_Ap);
-  free_batch(ctx); free_batch_state(ctx->fluxb); free_amg(ctx); free_responses(ctx); proj_free(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
+  free_batch(ctx); free_batch_state(ctx->fluxb); free_batch_cols(ctx); free_amg(ctx); free_responses(ctx); proj_free(ctx); dev_free(&ctx->d_z); dev_free(&ctx->d_z2);
   dev_free(&ctx->d_M1); dev_free(&ctx->d_dinv1); dev_free(&ctx->d_gz); dev_free(&ctx->d_gr); dev_free(&ctx->d_bz); dev_free(&ctx->d_br);
   dev_free(&ctx->d_tmp); dev_free(&ctx->d_part_pAp); dev_free(&ctx->d_part_rz); dev_free(&ctx->d_part_zz);
-  dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp);
+  dev_free(&ctx->d_part_bn); dev_free(&ctx->d_scal); dev_free(&ctx->d_samp_idx); dev_free(&ctx->d_samp); dev_free(&ctx->d_fsamp_idx);
   for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->h_mirror) (void)hipHostFree(ctx->h_mirror);
@@ -633,7 +712,7 @@ int hf_flux_solve(hf_ctx* ctx, int32_t components, double rtol, int32_t max_it, 
     hipLaunchKernelGGL(k_grad_rows, dim3(grid), dim3(RBA), sm, ctx->stream, ctx->nblk_a, capd, ctx->d_rg_hdr,
                        reinterpret_cast<const uint4*>(ctx->d_rg_ell), reinterpret_cast<const uint4*>(ctx->d_rg_cid), ctx->d_rg_zrb,
                        ctx->d_rg_dict, ctx->d_rowptr, ctx->d_u, both ? ctx->fluxb.b : ctx->d_bz, both ? ctx->fluxb.b + 1 : ctx->d_br,
-                       both ? 2 : 1);
+                       both ? 2 : 1, 1, 0);
   } else {
     HF_TRY(ensure_owner_lists(ctx));
     hipLaunchKernelGGL(k_grad_rhs, dim3(ctx->nblk_a), dim3(RBA), 0, ctx->stream, ctx->n, ctx->d_blk_eptr, ctx->d_blk_ent,
@@ -851,7 +930,8 @@ int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t operator_kind) {
   if (hipHostMalloc(reinterpret_cast<void**>(&B.h_mirror), sizeof(ScalMirror) * nv, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer(reinterpret_cast<void**>(&B.d_mirror), B.h_mirror, 0) != hipSuccess)
     return fail(ctx, HF_ERR_ALLOC, "hipHostMalloc (mapped) failed");
-  for (int j = 0; j < nv; ++j) B.h_mirror[j] = ScalMirror{0.0, 0.0, 0, 0, -1};
+  for (int j = 0; j < nv; ++j) B.h_mirror[j] = ScalMirror{};
+  B.epoch = 0;
   const int rpb = TPB / nv;
   B.Pb = static_cast<int>(std::min<size_t>((n + rpb - 1) / rpb, MAXP));
   if (B.Pb >= 64) B.Pb &= ~7;
@@ -880,6 +960,8 @@ int hf_batch_begin(hf_ctx* ctx, int32_t nv, int32_t operator_kind) {
     }
   }
   HF_HIP(hipStreamSynchronize(ctx->stream));
+  HF_TRY(ensure_batch_cols(ctx, nv));
+  B.lds = ctx->bcols.nv == nv;
   B.nv = nv;
   B.have_prev = false;
   B.pred_iters = 0;
@@ -998,6 +1080,12 @@ int hf_batch_get_state(hf_ctx* ctx, int32_t j, double* u) {
 
 int hf_batch_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, double atol, int32_t max_it, int32_t ns,
                  const int32_t* nodes, double* samples, int32_t* iters) {
+  return hf_batch_run_flux(ctx, n_steps, g_all, rtol, atol, max_it, ns, nodes, samples, iters, 0, 0.0, 0, 0, nullptr, nullptr, nullptr);
+}
+
+int hf_batch_run_flux(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol, double atol, int32_t max_it, int32_t ns,
+                      const int32_t* nodes, double* samples, int32_t* iters, int32_t flux_components, double flux_rtol,
+                      int32_t flux_max_it, int32_t nfs, const int32_t* flux_nodes, double* flux_samples, int32_t* flux_iters) {
   if (!ctx) return HF_ERR_ARG;
   hf_ctx::Batch& B = ctx->batch;
   if (B.nv == 0) return fail(ctx, HF_ERR_STATE, "hf_batch_run: no batch is open");
@@ -1008,10 +1096,25 @@ int hf_batch_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol,
   if (ns < 0 || (ns > 0 && (!nodes || !samples))) return fail(ctx, HF_ERR_ARG, "hf_batch_run: bad sample arguments");
   for (int32_t q = 0; q < ns; ++q)
     if (nodes[q] < 0 || nodes[q] >= ctx->n) return fail(ctx, HF_ERR_ARG, "hf_batch_run: node %d outside [0,%d)", nodes[q], ctx->n);
+  const int ncomp = (flux_components & 1) + ((flux_components >> 1) & 1);
+  if (flux_components != 0) {
+    if (flux_components < 0 || flux_components > 3 || flux_max_it <= 0 || flux_rtol < 0 || nfs <= 0 || !flux_nodes || !flux_samples)
+      return fail(ctx, HF_ERR_ARG, "hf_batch_run_flux: bad flux arguments");
+    if (!ctx->flux_ready) return fail(ctx, HF_ERR_STATE, "hf_batch_run_flux before hf_flux_setup");
+    if (!ctx->rg_ok) return fail(ctx, HF_ERR_ARG, "hf_batch_run_flux: the row-gather lists are not available for this mesh (a row of more than 32 entries or more than 64 cell tags): project run by run");
+    for (int32_t q = 0; q < nfs; ++q)
+      if (flux_nodes[q] < 0 || flux_nodes[q] >= ctx->n) return fail(ctx, HF_ERR_ARG, "hf_batch_run_flux: node %d outside [0,%d)", flux_nodes[q], ctx->n);
+  }
   HF_HIP(hipSetDevice(ctx->dev));
   const int nv = B.nv;
   const size_t gstep = static_cast<size_t>(ctx->nbc) * nv;
-  DevTemp<double> t_sall;
+  DevTemp<double> t_sall, t_fall;
+  if (flux_components != 0) {
+    HF_TRY(ensure_batch_flux(ctx, nv, ncomp));
+    if (nfs > ctx->fsamp_cap) { HF_TRY(dev_alloc(ctx, &ctx->d_fsamp_idx, nfs)); ctx->fsamp_cap = nfs; }
+    HF_HIP(copy_sync(ctx, ctx->d_fsamp_idx, flux_nodes, sizeof(int32_t) * nfs, hipMemcpyHostToDevice));
+    HF_TRY(dev_alloc(ctx, &t_fall.p, static_cast<size_t>(n_steps) * ncomp * nv * nfs));
+  }
   if (ctx->nbc > 0) {
     HF_TRY(dev_alloc(ctx, &B.g, gstep * n_steps));
     HF_HIP(copy_sync(ctx, B.g, g_all, sizeof(double) * gstep * n_steps, hipMemcpyHostToDevice));
@@ -1038,6 +1141,9 @@ int hf_batch_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol,
         default: hipLaunchKernelGGL((kb_gather<16>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ns, ctx->d_samp_idx, B.u, out); break;
       }
     }
+    if (flux_components != 0 && rc == HF_OK)
+      rc = batch_flux_step(ctx, flux_components, flux_rtol, flux_max_it, nfs, t_fall.p + static_cast<size_t>(s) * ncomp * nv * nfs,
+                           flux_iters ? flux_iters + static_cast<size_t>(s) * ncomp : nullptr);
   }
   (void)hipEventRecord(ctx->ev1, ctx->stream);
   (void)hipStreamSynchronize(ctx->stream);
@@ -1045,6 +1151,8 @@ int hf_batch_run(hf_ctx* ctx, int32_t n_steps, const double* g_all, double rtol,
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->last_ms = ms;
   if (ns > 0 && rc == HF_OK) (void)copy_sync(ctx, samples, t_sall.p, sizeof(double) * n_steps * nv * ns, hipMemcpyDeviceToHost);
+  if (flux_components != 0 && rc == HF_OK)
+    (void)copy_sync(ctx, flux_samples, t_fall.p, sizeof(double) * n_steps * ncomp * nv * nfs, hipMemcpyDeviceToHost);
   return rc;
 }
 

@@ -12,7 +12,8 @@
 //     converged column freezes (its x and r are no longer touched) while the others finish;
 //   * at stock mesh sizes, where a single run is launch-bound, NV columns per launch cost about one.
 // The algorithm per column is exactly hf_step's (same kernels' arithmetic, same stopping rule); the start vector
-// is the plain extrapolation 2 u^n - u^{n-1} (hf_set_start_vector kind 1).
+// is, per column, the A-norm projection of the new solution on the span of that column's last solutions
+// (hf_set_start_vector kind 3 without the boundary responses; kb_proj_*).
 #pragma once
 #include "hf_solver.hpp"
 
@@ -79,9 +80,12 @@ __global__ __launch_bounds__(TPB) void kb_reduce(int P, int nv, const double* __
   const double t = block_sum(v, s4);
   if (threadIdx.x == 0) {
     (second ? out_b : out_a)[j] = t;
-    if (test != nullptr && !second) {
+    // A column that had converged before this launch publishes nothing more: the launches of a blind first burst that
+    // run past the convergence of every column must not write into the mirrors the host may already be reading for the
+    // next solve (what they would write carries the old epoch besides, so even a late store cannot be taken for progress)
+    if (test != nullptr && !second && test[j].done != 1) {
       if (test[j].done == 0 && t <= test[j].tol2) { test[j].zz = t; test[j].done = 1; }
-      if (mirror != nullptr) mirror_publish(mirror + j, t, test[j].iters, test[j].done);
+      if (mirror != nullptr) mirror_publish(mirror + j, t, test[j].iters, test[j].done, test[j].epoch);
     }
   }
 }
@@ -204,6 +208,159 @@ __global__ __launch_bounds__(KB_BT) void kb_spmv(int n, const int32_t* __restric
   }
 }
 
+
+// The same operation with the chunk's operands staged in LDS (what k_spmv's C16 path does for one column): a workgroup
+// takes chunks of `rpc` consecutive rows (a multiple of KB_BT / NV, chosen so that one launch is about one round of
+// resident workgroups); all lanes stream the chunk's matrix values (one array, or two for the affine family) and the
+// 16-bit column positions in nnz order - coalesced 8-byte lanes instead of eight rows' worth of scattered words per
+// wavefront - and gather the chunk's slice of x through its sorted column list ONCE: NV contiguous doubles per list
+// entry, own rows plus a halo, 1.3-1.5 entries per row.  After one barrier thread (row, column) walks its row in LDS:
+// value(s), position, operand.  The row's own operand x[row] of modes 4 / 8 / 9 comes from the staged slice (a chunk's
+// rows are a contiguous run of its sorted list).  Per column the products are added in CSR order, as in kb_spmv.
+// Shared and affine operators only: per-column values (NV doubles per nonzero) have no shared stream to stage.
+struct BComp {
+  const int32_t* cptr;    // chunk -> first entry of its column list (nchunks + 1)
+  const int32_t* dict;    // the lists (global column numbers, sorted per chunk)
+  const int32_t* own;     // position of the chunk's first row in its list
+  const uint16_t* id;     // per nonzero: position of its column in the chunk's list
+  int rpc, nchunks, cap_nnz /* even */, cap_dict;
+};
+
+template <int MODE, int NV, int OPK>
+__global__ __launch_bounds__(KB_BT) void kb_spmv_lds(int n, const int32_t* __restrict__ rowptr, const BOp op,
+                                                   const double* __restrict__ x, double* __restrict__ y, Scal* __restrict__ scal,
+                                                   double* __restrict__ part0, const double* __restrict__ bvec,
+                                                   const double* __restrict__ dinv, double* __restrict__ pvec,
+                                                   double* __restrict__ part1, double* __restrict__ part2, double w,
+                                                   const BRed* __restrict__ red, int parity, const BComp comp, int npart) {
+  static_assert(OPK != OP_PERCOL, "per-column values are not staged");
+  extern __shared__ double sdyn[];
+  __shared__ double sw[(KB_BT / 64) * NV];
+  double* sv0 = sdyn;                                                       // [cap_nnz]
+  double* sv1 = sdyn + comp.cap_nnz;                                        // [cap_nnz] (affine)
+  double* sx = sdyn + (OPK == OP_AFFINE ? 2 : 1) * comp.cap_nnz;            // [cap_dict * NV]
+  uint16_t* sid = reinterpret_cast<uint16_t*>(sx + static_cast<size_t>(comp.cap_dict) * NV);   // [cap_nnz]
+  constexpr int RPP = KB_BT / NV;                                           // rows per pass
+  const int j = threadIdx.x % NV, rl = threadIdx.x / NV;
+  Scal* sc = scal + j;
+  bool active = true;
+  if (MODE == 3 || MODE == 4 || MODE == 9) active = sc->done == 0;
+  double beta = 0.0;
+  bool first9 = false;
+  if (MODE == 9) {
+    first9 = sc->first != 0;
+    const double rz_new = red->rz[parity][j], rz_old = red->rz[parity ^ 1][j], zz = red->zz[j];
+    if (active && !first9) {
+      const bool conv = zz <= sc->tol2;
+      if (blockIdx.x == 0 && rl == 0) {
+        sc->zz = zz;
+        if (conv) sc->done = 1;
+      }
+      if (conv) active = false;
+      beta = rz_new / rz_old;
+    }
+  }
+  // a workgroup whose columns have all ended has nothing to stage (the kernels of a blind burst after convergence)
+  const bool any_active = __syncthreads_or(active ? 1 : 0) != 0;
+  const double dj = OPK == OP_AFFINE ? op.delta[j] : 0.0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  const ChunkIter sched(comp.nchunks);
+  for (int chunk = sched.chunk; any_active && chunk < sched.end; chunk += sched.step) {
+    const int r0 = chunk * comp.rpc, r1 = min(n, r0 + comp.rpc);
+    const int k0 = rowptr[r0], nk = rowptr[r1] - k0;
+    const int d0 = comp.cptr[chunk], nd = comp.cptr[chunk + 1] - d0;
+    // ---- stage: matrix stream (values + positions), then the operand slice through the column list
+    for (int k = threadIdx.x; k < nk; k += 2 * KB_BT) {
+      const bool two = k + KB_BT < nk;
+      const double a0 = op.v0[k0 + k], b0 = two ? op.v0[k0 + k + KB_BT] : 0.0;
+      double a1 = 0.0, b1 = 0.0;
+      if (OPK == OP_AFFINE) { a1 = op.v1[k0 + k]; b1 = two ? op.v1[k0 + k + KB_BT] : 0.0; }
+      const uint16_t ia = comp.id[k0 + k], ib = two ? comp.id[k0 + k + KB_BT] : static_cast<uint16_t>(0);
+      sv0[k] = a0; sid[k] = ia;
+      if (OPK == OP_AFFINE) sv1[k] = a1;
+      if (two) {
+        sv0[k + KB_BT] = b0; sid[k + KB_BT] = ib;
+        if (OPK == OP_AFFINE) sv1[k + KB_BT] = b1;
+      }
+    }
+    const int nx = nd * NV;
+    for (int i = threadIdx.x; i < nx; i += 2 * KB_BT) {
+      const bool two = i + KB_BT < nx;
+      const int c0 = comp.dict[d0 + i / NV], c1 = two ? comp.dict[d0 + (i + KB_BT) / NV] : 0;     // KB_BT is a multiple of NV: i % NV == j
+      const double x0 = x[static_cast<size_t>(c0) * NV + j], x1 = two ? x[static_cast<size_t>(c1) * NV + j] : 0.0;
+      sx[i] = x0;
+      if (two) sx[i + KB_BT] = x1;
+    }
+    const int own = comp.own[chunk];
+    __syncthreads();
+    // ---- products: thread (row, column), RPP rows per pass
+    for (int rb = r0; rb < r1; rb += RPP) {
+      const int row = rb + rl;
+      if (row >= r1 || !active) continue;
+      const int pa = rowptr[row] - k0, pb = rowptr[row + 1] - k0;
+      const size_t o = static_cast<size_t>(row) * NV + j;
+      double e_b = 0.0, e_d = 0.0, e_y = 0.0, e_p = 0.0, e_x = 0.0;
+      if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 8) e_b = bvec[o];
+      if (MODE == 2 || MODE == 4 || MODE == 5) e_d = OPK != OP_SHARED ? dinv[o] : dinv[row];
+      if (MODE == 9 && !first9) { e_y = y[o]; e_p = pvec[o]; }
+      if (MODE == 4 || MODE == 8 || MODE == 9) e_x = sx[static_cast<size_t>(own + (row - r0)) * NV + j];
+      double s = 0.0;
+      for (int k = pa; k < pb; ++k) {
+        const double v = OPK == OP_AFFINE ? sv0[k] + dj * sv1[k] : sv0[k];
+        s += v * sx[static_cast<int>(sid[k]) * NV + j];
+      }
+      if (MODE == 0) {
+        y[o] = s;
+      } else if (MODE == 2) {
+        const double ri = e_b - s, zi = e_d * ri;
+        y[o] = ri;
+        pvec[o] = zi;
+        acc0 += ri * zi;
+        acc1 += zi * zi;
+        acc2 += (e_d * e_b) * (e_d * e_b);
+      } else if (MODE == 3) {
+        y[o] = e_b - s;
+      } else if (MODE == 4) {
+        const double yi = e_x + w * e_d * (e_b - s);
+        y[o] = yi;
+        acc0 += e_b * yi;
+      } else if (MODE == 5) {
+        const double ri = e_b - s;
+        y[o] = ri;
+        pvec[o] = w * e_d * ri;
+        acc1 += (e_d * ri) * (e_d * ri);
+        acc2 += (e_d * e_b) * (e_d * e_b);
+      } else if (MODE == 8) {
+        y[o] = s;
+        pvec[o] = 2.0 * e_x - e_b;
+      } else {
+        const double api = first9 ? s : s + beta * e_y;
+        const double pi = first9 ? e_x : e_x + beta * e_p;
+        y[o] = api;
+        pvec[o] = pi;
+        acc0 += pi * api;
+      }
+    }
+    __syncthreads();
+  }
+  // the consumers (kb_reduce) add `npart` slots per column: this launch may have fewer workgroups, the rest are zeros
+  if (MODE == 2 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {
+    const double t0 = block_colsum<NV, KB_BT / 64>(acc0, sw);
+    if (rl == 0) {
+      part0[j * MAXP + blockIdx.x] = t0;
+      for (int q = blockIdx.x + gridDim.x; q < npart; q += gridDim.x) part0[j * MAXP + q] = 0.0;
+    }
+  }
+  if (MODE == 2 || MODE == 5) {
+    const double t1 = block_colsum<NV, KB_BT / 64>(acc1, sw);
+    const double t2 = block_colsum<NV, KB_BT / 64>(acc2, sw);
+    if (rl == 0) {
+      part1[j * MAXP + blockIdx.x] = t1; part2[j * MAXP + blockIdx.x] = t2;
+      for (int q = blockIdx.x + gridDim.x; q < npart; q += gridDim.x) { part1[j * MAXP + q] = 0.0; part2[j * MAXP + q] = 0.0; }
+    }
+  }
+}
+
 // Generic CSR operator (shared values) times NV interleaved columns: LANES lanes share a row, each keeps NV
 // accumulators, so every index and value is read once.  VMODE 0: y = A x, 1: y += A x.
 template <int NV, int LANES, int VMODE, typename VT>
@@ -282,7 +439,8 @@ __global__ __launch_bounds__(TPB) void kb_scale(int n, double w, const double* _
 template <int NV>
 __global__ __launch_bounds__(TPB) void kb_begin(int P, double rtol, double atol, const double* __restrict__ part_zz,
                                                 const double* __restrict__ part_bn, const double* __restrict__ part_rz0,
-                                                Scal* __restrict__ scal, BRed* __restrict__ red, ScalMirror* __restrict__ mirror) {
+                                                Scal* __restrict__ scal, BRed* __restrict__ red, ScalMirror* __restrict__ mirror,
+                                                unsigned epoch) {
   __shared__ double sw[4 * NV];
   const int j = threadIdx.x % NV;
   const double zz = col_partials<NV>(part_zz + j * MAXP, P, sw);
@@ -298,12 +456,13 @@ __global__ __launch_bounds__(TPB) void kb_begin(int P, double rtol, double atol,
     sc->iters = 0;
     sc->first = 1;
     sc->done = (zz <= tol * tol) ? 1 : 0;
+    sc->epoch = epoch;
     red->zz[j] = zz;
     red->bn[j] = bn2;
     if (part_rz0 != nullptr) red->rz[0][j] = rz0;
     if (mirror != nullptr) {
       mirror[j].bn2 = bn2;
-      mirror_publish(mirror + j, zz, 0, sc->done);
+      mirror_publish(mirror + j, zz, 0, sc->done, epoch);
     }
   }
 }
@@ -508,7 +667,69 @@ void free_batch_state(hf_ctx::Batch& B) {
   B.sysA = B.sysDinv = nullptr;
 }
 
-void free_batch(hf_ctx* ctx) { free_batch_state(ctx->batch); }
+void free_batch(hf_ctx* ctx) { free_batch_state(ctx->batch); free_batch_state(ctx->fluxnb); }
+
+void free_batch_cols(hf_ctx* ctx) {
+  hf_ctx::BatchCols& T = ctx->bcols;
+  dev_free(&T.ptr); dev_free(&T.dict); dev_free(&T.own); dev_free(&T.id);
+  T = hf_ctx::BatchCols();
+}
+
+size_t batch_lds_bytes(int cap_nnz, int cap_dict, int nv, bool affine) {
+  return (static_cast<size_t>(affine ? 2 : 1) * cap_nnz + static_cast<size_t>(cap_dict) * nv) * 8 + ((static_cast<size_t>(cap_nnz) * 2 + 7) & ~static_cast<size_t>(7));
+}
+
+// Tables of kb_spmv_lds for `nv` columns.  Rows per chunk: a multiple of the rows one pass of the workgroup covers
+// (KB_BT / nv), as many as make the launch about one round of resident workgroups (<= MAXP chunks where the mesh allows it,
+// at most 4 passes), fewer if the chunk's operands would not fit the 64-KB LDS window of a launch.  HEATFLOW_BATCH_LDS=0
+// keeps the gather kernel (A/B); HEATFLOW_BATCH_RPC overrides the rows per chunk.
+int ensure_batch_cols(hf_ctx* ctx, int nv) {
+  static const bool enabled = !(std::getenv("HEATFLOW_BATCH_LDS") && std::getenv("HEATFLOW_BATCH_LDS")[0] == '0');
+  hf_ctx::BatchCols& T = ctx->bcols;
+  if (!enabled) { free_batch_cols(ctx); return HF_OK; }
+  if (T.nv == nv) return HF_OK;
+  free_batch_cols(ctx);
+  const int rpp = KB_BT / nv;
+  int m = static_cast<int>(std::min<long long>(4, std::max<long long>(1, (static_cast<long long>(ctx->n) + static_cast<long long>(rpp) * MAXP - 1) / (static_cast<long long>(rpp) * MAXP))));
+  if (const char* e = std::getenv("HEATFLOW_BATCH_RPC")) m = std::max(1, std::atoi(e) / rpp);
+  for (; m >= 1; --m) {
+    const int rpc = m * rpp;
+    ColDict D;
+    if (!build_coldict(ctx->h_rowptr, ctx->h_colidx, ctx->n, rpc, D)) continue;
+    const int nch = (ctx->n + rpc - 1) / rpc;
+    int cap = 0;
+    for (int c = 0; c < nch; ++c) cap = std::max(cap, ctx->h_rowptr[std::min<int64_t>(ctx->n, (c + 1LL) * rpc)] - ctx->h_rowptr[static_cast<size_t>(c) * rpc]);
+    cap = (cap + 1) & ~1;
+    if (batch_lds_bytes(cap, D.max_dict, nv, true) > 64 * 1024) continue;
+    // position of each chunk's first row in its list; the rows of a chunk must be a contiguous run of it (every row
+    // stores its diagonal: true for the P1 pattern) - otherwise the staged kernel is not used
+    std::vector<int32_t> own(nch);
+    bool ok = true;
+    for (int c = 0; c < nch && ok; ++c) {
+      const int32_t r0 = c * rpc, r1 = std::min<int32_t>(ctx->n, r0 + rpc);
+      const int32_t* lo = D.dict.data() + D.ptr[c];
+      const int32_t* hi = D.dict.data() + D.ptr[c + 1];
+      const int32_t* at = std::lower_bound(lo, hi, r0);
+      ok = hi - at >= r1 - r0 && at[0] == r0 && at[r1 - r0 - 1] == r1 - 1;
+      own[c] = static_cast<int32_t>(at - lo);
+    }
+    if (!ok) return HF_OK;
+    HF_TRY(dev_alloc(ctx, &T.ptr, D.ptr.size()));
+    HF_TRY(dev_alloc(ctx, &T.dict, D.dict.size()));
+    HF_TRY(dev_alloc(ctx, &T.own, own.size()));
+    HF_TRY(dev_alloc(ctx, &T.id, D.id.size()));
+    HF_HIP(copy_sync(ctx, T.ptr, D.ptr.data(), sizeof(int32_t) * D.ptr.size(), hipMemcpyHostToDevice));
+    HF_HIP(copy_sync(ctx, T.dict, D.dict.data(), sizeof(int32_t) * D.dict.size(), hipMemcpyHostToDevice));
+    HF_HIP(copy_sync(ctx, T.own, own.data(), sizeof(int32_t) * own.size(), hipMemcpyHostToDevice));
+    HF_HIP(copy_sync(ctx, T.id, D.id.data(), sizeof(uint16_t) * D.id.size(), hipMemcpyHostToDevice));
+    T.nv = nv; T.rpc = rpc; T.nchunks = nch; T.cap_nnz = cap; T.cap_dict = D.max_dict;
+    if (std::getenv("HEATFLOW_DEBUG"))
+      std::fprintf(stderr, "[batch] nv %d: %d chunks of %d rows, <= %d nonzeros and %d list entries per chunk (%.2f per row), LDS %zu B (affine)\n", nv, nch, rpc, cap,
+                   D.max_dict, static_cast<double>(D.dict.size()) / ctx->n, batch_lds_bytes(cap, D.max_dict, nv, true));
+    return HF_OK;
+  }
+  return HF_OK;     // no chunk size fits: the gather kernel stays
+}
 
 template <int NV, int VMODE, typename VT>
 void blaunch_csr_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y) {
@@ -560,6 +781,23 @@ struct BatchOps {
   static void spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr, const double* bvec = nullptr,
                    double* pvec = nullptr, double* part1 = nullptr, double* part2 = nullptr, double w = 0.0, int parity = 0) {
     hf_ctx::Batch& B = c->batch;
+    if (B.lds && OPK != OP_PERCOL) {    // chunk operands staged in LDS, 16-bit column positions
+      const hf_ctx::BatchCols& T = c->bcols;
+      const BComp comp{T.ptr, T.dict, T.own, T.id, T.rpc, T.nchunks, T.cap_nnz, T.cap_dict};
+      int grid = std::min(T.nchunks, B.Pb);
+      if (grid >= 64) grid &= ~7;
+      if (vals == c->d_M) {
+        BOp m{};
+        m.v0 = c->d_M;
+        hipLaunchKernelGGL((kb_spmv_lds<MODE, NV, OP_SHARED>), dim3(grid), dim3(KB_BT), batch_lds_bytes(T.cap_nnz, T.cap_dict, NV, false), c->stream,
+                           c->n, c->d_rowptr, m, x, y, B.scal, part0, bvec, c->d_dinv, pvec, part1, part2, w, B.red, parity, comp, B.Pb);
+      } else {
+        constexpr int OPL = OPK == OP_PERCOL ? OP_SHARED : OPK;     // (never instantiated for per-column values)
+        hipLaunchKernelGGL((kb_spmv_lds<MODE, NV, OPL>), dim3(grid), dim3(KB_BT), batch_lds_bytes(T.cap_nnz, T.cap_dict, NV, OPL == OP_AFFINE), c->stream,
+                           c->n, c->d_rowptr, Aop(c), x, y, B.scal, part0, bvec, Dinv(c), pvec, part1, part2, w, B.red, parity, comp, B.Pb);
+      }
+      return;
+    }
     // M is always shared (rho_c does not change inside a batch): MODE 0 / 8 on M use the shared-value kernel
     if (vals == c->d_M) {
       BOp m{};
@@ -651,14 +889,20 @@ struct BatchOps {
   static int wait_tested(hf_ctx* ctx, int k, bool* all_done, int* max_iters, bool* breakdown) {
     static const double limit_s = std::getenv("HEATFLOW_POLL_TIMEOUT_S") ? std::atof(std::getenv("HEATFLOW_POLL_TIMEOUT_S")) : 60.0;
     hf_ctx::Batch& B = ctx->batch;
+    const unsigned ep = B.epoch;
     const auto t0 = std::chrono::steady_clock::now();
+    auto last_query = t0;
     auto reached = [&]() {
       for (int j = 0; j < NV; ++j)
-        if (__atomic_load_n(&B.h_mirror[j].tested, __ATOMIC_ACQUIRE) < k && __atomic_load_n(&B.h_mirror[j].done, __ATOMIC_ACQUIRE) == 0) return false;
+        if (mirror_tested(B.h_mirror + j, ep) < k && mirror_done(B.h_mirror + j, ep) == 0) return false;
       return true;
     };
     for (unsigned spin = 1; !reached(); ++spin) {
-      if ((spin & 0xfff) != 0) continue;
+      cpu_relax();
+      if ((spin & 0x3ff) != 0) continue;
+      const auto now = std::chrono::steady_clock::now();
+      if (now - last_query < std::chrono::milliseconds(2)) continue;   // the runtime lock hipStreamQuery takes is the one other sessions' launch threads need
+      last_query = now;
       if (hipStreamQuery(ctx->stream) == hipSuccess) {
         if (reached()) break;
         return fail(ctx, HF_ERR_HIP, "batched PCG progress: stream drained before the test of iteration %d ran (%s)", k, hipGetErrorString(hipGetLastError()));
@@ -671,7 +915,7 @@ struct BatchOps {
     for (int j = 0; j < NV; ++j) {
       const ScalMirror& m = B.h_mirror[j];
       B.h_scal[j].iters = m.iters; B.h_scal[j].zz = m.zz; B.h_scal[j].bn2 = m.bn2;
-      B.h_scal[j].done = __atomic_load_n(&B.h_mirror[j].done, __ATOMIC_ACQUIRE);
+      B.h_scal[j].done = mirror_done(B.h_mirror + j, ep);
       if (!B.h_scal[j].done) *all_done = false;
       if (B.h_scal[j].done == 2) *breakdown = true;
       *max_iters = std::max(*max_iters, B.h_scal[j].iters);
@@ -682,19 +926,17 @@ struct BatchOps {
   // PCG on all columns, started from B.u; iteration counts / residuals are left in B.h_scal
   static int pcg(hf_ctx* ctx, bool use_amg, double rtol, double atol, int max_it) {
     hf_ctx::Batch& B = ctx->batch;
-    if (B.h_mirror != nullptr)     // the previous solve has ended: nothing in flight writes the mirrors
-      for (int j = 0; j < NV; ++j) {
-        __atomic_store_n(&B.h_mirror[j].done, 0, __ATOMIC_RELAXED);
-        __atomic_store_n(&B.h_mirror[j].tested, -1, __ATOMIC_RELEASE);
-      }
+    // a new epoch instead of a reset of the mirrors: launches of the previous solve's blind burst may still be queued
+    // (they publish nothing once their column has converged, and whatever reaches the mirrors late carries the old epoch)
+    B.epoch += 1;
     HF_HIP(hipMemsetAsync(B.scal, 0, sizeof(Scal) * NV, ctx->stream));
     if (!use_amg) {
       spmv<2>(ctx, Avals(ctx), B.u, B.r, B.part_rz, B.b, B.z, B.part_zz, B.part_bn, 0.0);
-      hipLaunchKernelGGL((kb_begin<NV>), dim3(1), dim3(TPB), 0, ctx->stream, B.Pb, rtol, atol, B.part_zz, B.part_bn, B.part_rz, B.scal, B.red, B.d_mirror);
+      hipLaunchKernelGGL((kb_begin<NV>), dim3(1), dim3(TPB), 0, ctx->stream, B.Pb, rtol, atol, B.part_zz, B.part_bn, B.part_rz, B.scal, B.red, B.d_mirror, B.epoch);
     } else {
       spmv<5>(ctx, Avals(ctx), B.u, B.r, nullptr, B.b, B.z, B.part_zz, B.part_bn, ctx->amg[0].omega);
       hipLaunchKernelGGL((kb_begin<NV>), dim3(1), dim3(TPB), 0, ctx->stream, B.Pb, rtol, atol, B.part_zz, B.part_bn,
-                         static_cast<const double*>(nullptr), B.scal, B.red, B.d_mirror);
+                         static_cast<const double*>(nullptr), B.scal, B.red, B.d_mirror, B.epoch);
       vcycle(ctx, 0);
     }
     HF_HIP(hipGetLastError());

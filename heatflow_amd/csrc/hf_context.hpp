@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "amg_host.hpp"
@@ -43,12 +44,25 @@ constexpr int TS = 512;        // SpMV workgroup: 512 threads = 8 wavefronts own
 // Host-visible progress of the running solve (pinned, mapped memory): written by the one thread that changes the
 // device-resident scalars, so the host follows the convergence tests by reading its own memory - no copy, no
 // synchronisation - and queues the next iteration while the current V-cycle is still running.
+// `done` and `tested` carry the epoch of the solve that wrote them in their upper half (Scal::epoch, bumped by the host for
+// every solve): launches of an earlier solve that are still queued when the host has moved on (the blind first burst can
+// run past convergence) cannot be mistaken for progress of the current one, and the host never has to reset the mirror
+// while something that writes it may still be in flight.
 struct ScalMirror {
   double zz, bn2;
   int iters;                   // updates done when the last test ran
-  int done;                    // as Scal::done
-  int tested;                  // -1 until the start kernel has run, then the iteration count whose iterate was tested last
+  int pad_;
+  unsigned long long done_st;    // (epoch << 32) | Scal::done
+  unsigned long long tested_st;  // (epoch << 32) | (iteration count whose iterate was tested last + 1); the start kernel writes + 1 = "0 tested"
 };
+inline int mirror_tested(const ScalMirror* m, unsigned epoch) {   // host side: -1 until the current solve's start kernel has run
+  const unsigned long long v = __atomic_load_n(&m->tested_st, __ATOMIC_ACQUIRE);
+  return static_cast<unsigned>(v >> 32) == epoch ? static_cast<int>(v & 0xffffffffu) - 1 : -1;
+}
+inline int mirror_done(const ScalMirror* m, unsigned epoch) {
+  const unsigned long long v = __atomic_load_n(&m->done_st, __ATOMIC_ACQUIRE);
+  return static_cast<unsigned>(v >> 32) == epoch ? static_cast<int>(v & 0xffffffffu) : 0;
+}
 
 struct Scal {                  // device-resident PCG scalars
   double tol2;                 // (max(rtol*||D^-1 b||, atol))^2
@@ -57,6 +71,7 @@ struct Scal {                  // device-resident PCG scalars
   int iters;
   int done;                    // 0 running, 1 converged, 2 breakdown
   int first;                   // 1 until the first update of a solve: the first direction is p = z (beta = 0)
+  unsigned epoch;              // the host's count of solves on this context (k_pcg_begin / kb_begin): stamps what goes to the mirror
   ScalMirror* mirror;          // device address of the host mirror, or null (batched columns)
 };
 
@@ -154,6 +169,7 @@ struct hf_ctx {
   Scal* h_scal = nullptr;      // pinned
   ScalMirror* h_mirror = nullptr;   // pinned + mapped; d_mirror is its device address
   ScalMirror* d_mirror = nullptr;
+  unsigned epoch = 0;          // solves started on this context (Scal::epoch)
   int32_t* d_samp_idx = nullptr;
   double* d_samp = nullptr;
   int samp_cap = 0;
@@ -210,6 +226,7 @@ struct hf_ctx {
     double *part_pAp = nullptr, *part_rz = nullptr, *part_zz = nullptr, *part_bn = nullptr;
     Scal *scal = nullptr, *h_scal = nullptr;
     ScalMirror *h_mirror = nullptr, *d_mirror = nullptr;   // per-column progress for the host (pinned + mapped), hf_batch_begin only
+    unsigned epoch = 0;          // solves started on this batch state (Scal::epoch of every column)
     BRed* red = nullptr;         // per-column reduced scalars
     std::vector<BatchLevel> lev;
     int Pb = 0, pred_iters = 0;
@@ -219,8 +236,19 @@ struct hf_ctx {
     bool pused[6] = {false};
     int pnext = 0, ppending = -1;
     unsigned loaded = 0;         // bit j: column j's operator has been loaded (percol)
+    bool lds = false;            // fine-pattern products through kb_spmv_lds (the context's `bcols` tables are for this nv)
   } batch;
+  // compressed columns of the batched loop's LDS-staged SpMV (BComp in hf_batch.hpp): per chunk of `rpc` rows a sorted
+  // column list and per nonzero a 16-bit position in it; built on the first hf_batch_begin with a given nv, kept per mesh
+  struct BatchCols {
+    int nv = 0, rpc = 0, nchunks = 0, cap_nnz = 0, cap_dict = 0;
+    int32_t *ptr = nullptr, *dict = nullptr, *own = nullptr;
+    uint16_t* id = nullptr;
+  } bcols;
   Batch fluxb;                   // two-column state of the read-flux projection (both components in one PCG), swapped into `batch` while it runs
+  Batch fluxnb;                  // nv-column state of the batched loop's read-flux projection (hf_batch_run_flux): one gradient component of every column per PCG
+  int32_t* d_fsamp_idx = nullptr;   // its sample nodes
+  int fsamp_cap = 0;
   // optional in-situ kernel timing (hf_set_profile): event pairs around each PCG SpMV launch
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
@@ -232,6 +260,15 @@ struct hf_ctx {
 namespace {
 
 int fail(hf_ctx* c, int code, const char* fmt, ...);
+
+// a polite spin: the polling threads of concurrent sessions share host cores with the threads that launch kernels
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
 
 hipError_t copy_sync(hf_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
   if (bytes == 0) return hipSuccess;

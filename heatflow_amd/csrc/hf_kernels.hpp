@@ -365,7 +365,8 @@ __global__ __launch_bounds__(RBA) void k_grad_rows(int nblk, int capd, const int
                                                    const uint4* __restrict__ cid16, const double2* __restrict__ zrb,
                                                    const int32_t* __restrict__ dict, const int32_t* __restrict__ rowptr,
                                                    const double* __restrict__ u, double* __restrict__ bz, double* __restrict__ br,
-                                                   int stride /* 1: two arrays; 2: bz = out, br = out + 1 interleaved */) {
+                                                   int stride /* of the outputs - 1: plain arrays; 2: bz = out, br = out + 1 interleaved; nv: column j of an interleaved batch vector */,
+                                                   int ustride, int uoff /* the state is u[node * ustride + uoff] (batched loop: column uoff of nv) */) {
   extern __shared__ double smem[];
   double2* sXd = reinterpret_cast<double2*>(smem);
   double* sU = smem + 2 * capd;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(RBA) void k_grad_rows(int nblk, int capd, const int
     const int4 cA = hdr[2 * blk], cB = hdr[2 * blk + 1];
     const int c0 = cA.x >> 3, nc = ((cA.x + cA.y + 7) >> 3) - c0;
     for (int i = t; i < nc; i += RBA) sC4[i] = cid16[c0 + i];
-    for (int i = t; i < cA.w; i += RBA) { sXd[i] = zrb[cA.z + i]; sU[i] = u[dict[cA.z + i]]; }
+    for (int i = t; i < cA.w; i += RBA) { sXd[i] = zrb[cA.z + i]; sU[i] = u[static_cast<size_t>(dict[cA.z + i]) * ustride + uoff]; }
     if (t < cB.w) sR[t] = rowptr[blk * RBA + t] - cA.x;
     __syncthreads();
     if (t < cB.w) {
@@ -405,8 +406,8 @@ __global__ __launch_bounds__(RBA) void k_grad_rows(int nblk, int capd, const int
           ar += gr * wgt;
         }
       }
-      bz[static_cast<size_t>(blk * RBA + t) * stride] = az;
-      br[static_cast<size_t>(blk * RBA + t) * stride] = ar;
+      if (bz != nullptr) bz[static_cast<size_t>(blk * RBA + t) * stride] = az;
+      if (br != nullptr) br[static_cast<size_t>(blk * RBA + t) * stride] = ar;
     }
     __syncthreads();
   }
@@ -575,13 +576,19 @@ __global__ void k_gather(int ns, const int32_t* __restrict__ idx, const double* 
 // per nonzero instead of the 32-bit column.  The chunk's slice of x is staged in LDS once (an almost contiguous
 // gather) and the products look it up there: 10 instead of 12 bytes per nonzero, 5x fewer global gathers.
 // progress of the solve for the host (ScalMirror): payload first, then the counter the host polls
-__device__ __forceinline__ void mirror_publish(ScalMirror* m, double zz, int iters, int done) {
+__device__ __forceinline__ unsigned long long mirror_stamp(unsigned epoch, int v) {
+  return (static_cast<unsigned long long>(epoch) << 32) | static_cast<unsigned>(v);
+}
+__device__ __forceinline__ void mirror_publish(ScalMirror* m, double zz, int iters, int done, unsigned epoch) {
   if (m == nullptr) return;
   m->zz = zz;
   m->iters = iters;
-  __hip_atomic_store(&m->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&m->done_st, mirror_stamp(epoch, done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
-  __hip_atomic_store(&m->tested, iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&m->tested_st, mirror_stamp(epoch, iters + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void mirror_breakdown(ScalMirror* m, unsigned epoch) {
+  if (m != nullptr) __hip_atomic_store(&m->done_st, mirror_stamp(epoch, 2), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // own != 0 (square operators whose rows all store their diagonal): the chunk's own rows are a contiguous run of its sorted
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
     const bool conv = zz <= scal->tol2;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       if (conv) { scal->zz = zz; scal->done = 1; }
-      mirror_publish(scal->mirror, zz, scal->iters, conv ? 1 : 0);
+      mirror_publish(scal->mirror, zz, scal->iters, conv ? 1 : 0, scal->epoch);
     }
     if (conv) return;
   }
@@ -813,7 +820,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
 
 // PCG start: tolerance and convergence of the initial iterate (one workgroup).
 __global__ __launch_bounds__(TPB) void k_pcg_begin(int P, double rtol, double atol, const double* __restrict__ part_zz,
-                                                   const double* __restrict__ part_bn, Scal* __restrict__ scal) {
+                                                   const double* __restrict__ part_bn, Scal* __restrict__ scal, unsigned epoch) {
   __shared__ double s4[4];
   const double zz = sum_partials(part_zz, P, s4);
   const double bn2 = sum_partials(part_bn, P, s4);
@@ -827,8 +834,9 @@ __global__ __launch_bounds__(TPB) void k_pcg_begin(int P, double rtol, double at
     scal->iters = 0;
     scal->first = 1;
     scal->done = (zz <= tol * tol) ? 1 : 0;
+    scal->epoch = epoch;
     if (scal->mirror != nullptr) scal->mirror->bn2 = bn2;
-    mirror_publish(scal->mirror, zz, 0, scal->done);
+    mirror_publish(scal->mirror, zz, 0, scal->done, epoch);
   }
 }
 
@@ -846,7 +854,7 @@ __global__ __launch_bounds__(TPB) void k_pcg_update(int n, int nchunks, int P, i
   if (!(pAp > 0.0)) {                                   // breakdown (A_hat is SPD, so only on NaN/garbage)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       scal->done = 2;
-      if (scal->mirror != nullptr) __hip_atomic_store(&scal->mirror->done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      mirror_breakdown(scal->mirror, scal->epoch);
     }
     return;
   }
@@ -1290,7 +1298,7 @@ __global__ __launch_bounds__(TPB) void k_pcg_update_amg(int n, int nchunks, int 
   if (!(pAp > 0.0)) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       scal->done = 2;
-      if (scal->mirror != nullptr) __hip_atomic_store(&scal->mirror->done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      mirror_breakdown(scal->mirror, scal->epoch);
     }
     return;
   }

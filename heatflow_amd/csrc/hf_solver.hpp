@@ -384,14 +384,20 @@ int read_scal(hf_ctx* ctx) {
 int wait_tested(hf_ctx* ctx, int k) {
   static const double limit_s = std::getenv("HEATFLOW_POLL_TIMEOUT_S") ? std::atof(std::getenv("HEATFLOW_POLL_TIMEOUT_S")) : 60.0;
   ScalMirror* m = ctx->h_mirror;
+  const unsigned ep = ctx->epoch;
   const auto t0 = std::chrono::steady_clock::now();
+  auto last_query = t0;
   for (unsigned spin = 1;; ++spin) {
-    const int tested = __atomic_load_n(&m->tested, __ATOMIC_ACQUIRE);
-    const int done = __atomic_load_n(&m->done, __ATOMIC_ACQUIRE);
+    const int tested = mirror_tested(m, ep);
+    const int done = mirror_done(m, ep);
     if (tested >= k || done != 0) break;
-    if ((spin & 0xfff) == 0) {
+    cpu_relax();
+    if ((spin & 0x3ff) == 0) {
+      const auto now = std::chrono::steady_clock::now();
+      if (now - last_query < std::chrono::milliseconds(2)) continue;   // hipStreamQuery takes the runtime lock other sessions' launch threads need
+      last_query = now;
       if (hipStreamQuery(ctx->stream) == hipSuccess) {     // everything queued has run: the test we wait for was never launched, or a launch failed
-        if (__atomic_load_n(&m->tested, __ATOMIC_ACQUIRE) >= k || __atomic_load_n(&m->done, __ATOMIC_ACQUIRE) != 0) break;
+        if (mirror_tested(m, ep) >= k || mirror_done(m, ep) != 0) break;
         return fail(ctx, HF_ERR_HIP, "PCG progress: stream drained before the test of iteration %d ran (%s)", k, hipGetErrorString(hipGetLastError()));
       }
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
@@ -402,7 +408,7 @@ int wait_tested(hf_ctx* ctx, int k) {
   ctx->h_scal->iters = m->iters;
   ctx->h_scal->zz = m->zz;
   ctx->h_scal->bn2 = m->bn2;
-  ctx->h_scal->done = __atomic_load_n(&m->done, __ATOMIC_ACQUIRE);
+  ctx->h_scal->done = mirror_done(m, ep);
   return HF_OK;
 }
 
@@ -424,21 +430,20 @@ void harvest_profile(hf_ctx* ctx) {
 // Iteration count / residual are left in h_scal; *pred carries the burst-size hint between calls.
 int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double atol, int max_it, int* pred) {
   static const bool trace_res = std::getenv("HEATFLOW_TRACE_RES") != nullptr;   // diagnostics: bursts of 2, residual printed after each
-  // the previous solve has ended (its outcome was read), nothing in flight writes the mirror: reset it for this one
-  __atomic_store_n(&ctx->h_mirror->done, 0, __ATOMIC_RELAXED);
-  __atomic_store_n(&ctx->h_mirror->tested, -1, __ATOMIC_RELEASE);
+  // a new epoch: whatever an earlier solve's queued launches might still write to the mirror is not this solve's progress
+  ctx->epoch += 1;
   if (!use_amg) {
     // r = b - A x, z = D^-1 r, r.z
     launch_spmv<2>(ctx, sys.A, sys.x, ctx->d_r, ctx->d_part_rz, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn, 0.0,
                    sys.dinv);
     hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
-                       ctx->d_part_bn, ctx->d_scal);
+                       ctx->d_part_bn, ctx->d_scal, ctx->epoch);
   } else {
     // r = b - A x, z0 = w D^-1 r; tolerance; z = B r (V-cycle, r.z into slot 0)
     launch_spmv<5>(ctx, sys.A, sys.x, ctx->d_r, nullptr, sys.b, ctx->d_z, ctx->d_part_zz, ctx->d_part_bn,
                    ctx->amg[0].omega);
     hipLaunchKernelGGL(k_pcg_begin, dim3(1), dim3(TPB), 0, ctx->stream, ctx->P, rtol, atol, ctx->d_part_zz,
-                       ctx->d_part_bn, ctx->d_scal);
+                       ctx->d_part_bn, ctx->d_scal, ctx->epoch);
     vcycle(ctx, 0);
   }
   HF_HIP(hipGetLastError());

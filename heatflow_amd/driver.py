@@ -241,11 +241,12 @@ class SimulationSession:
             self._tree = cKDTree(self.coords)
         return names, np.array([self._tree.query(p)[1] for p in coords_w], dtype=np.int32)
 
-    def run_batch(self, cfgs, stacks, watcher_points=None):
+    def run_batch(self, cfgs, stacks, watcher_points=None, read_flux=False):
         """``len(cfgs)`` in (2, 4, 8, 16) simulations of this mesh advanced together (hf_batch_*): the points of a
         sweep that share geometry, time stepping and rho_c; they may differ in the boundary values (fwhm,
         heating curve: one shared operator) and in the conductivities (one operator per column, shared
-        frozen multigrid hierarchy).  Returns one result dict per configuration, as :meth:`run` does."""
+        frozen multigrid hierarchy).  ``read_flux`` adds run_no_diamond's per-step gradient projection for every
+        column (hf_batch_run_flux).  Returns one result dict per configuration, as :meth:`run` does."""
         nv = len(cfgs)
         if nv not in (2, 4, 8, 16):
             raise ValueError("run_batch: 2, 4, 8 or 16 configurations at a time")
@@ -294,6 +295,11 @@ class SimulationSession:
         names, nodes = self._watcher_nodes(watcher_points)
         if affine and mid[1] != self._k:
             self._revalue(mid[1], mid[2], allow_rebuild=False)     # the context's operator is the reference of the family
+        flux0 = FluxSampler(self.coords) if read_flux else None
+        if flux0 is not None and not getattr(prob, "_flux_ready", False):
+            print("Setting up radial heat flux sampling...")
+            be.flux_setup()                    # once per mesh: the unit-coefficient mass matrix does not depend on kappa
+            prob._flux_ready = True
         be.batch_begin(nv, per_column_operator=2 if affine else (1 if percol else 0))
         try:
             if affine:
@@ -307,16 +313,26 @@ class SimulationSession:
                 be.batch_set_state(j, np.full(prob.n, ic_temp))
             print("Beginning loop...")
             t_loop = time.time()
-            samples, iters = be.batch_run(g_all, self.rtol, 0.0, self.max_it, nodes)
+            if flux0 is None:
+                samples, iters = be.batch_run(g_all, self.rtol, 0.0, self.max_it, nodes)
+            else:                              # d/dr only, as the single run (run_no_diamond.py:553-566 reads nothing else)
+                samples, iters, grad = be.batch_run(g_all, self.rtol, 0.0, self.max_it, nodes, flux_nodes=flux0.nodes,
+                                                    flux_components=2, flux_rtol=self.rtol, flux_max_it=5000)
             loop_time = time.time() - t_loop
         finally:
             be.batch_end()
+        fluxes = [None] * nv
+        if flux0 is not None:
+            for j in range(nv):
+                fluxes[j] = flux0 if j == 0 else flux0.clone()
+                for s, t in enumerate(times):
+                    fluxes[j].record_sampled(t, grad[s, 0, j])
         print(f"Simulation progress: 100% (step {num_steps}/{num_steps}) | {nv} runs together | Avg time/step: "
               f"{loop_time / num_steps:.4f} s | PCG iterations/step: mean {np.mean(iters):.0f}, max {int(np.max(iters))}")
         return [{"times": times.copy(), "watcher_names": names,
                  "watchers": {nm: samples[:, j, k].copy() for k, nm in enumerate(names)},
                  "iters": iters[:, j].copy(), "loop_time": loop_time / nv, "startup_time": (t_loop - t_start) / nv,
-                 "n_dof": prob.n, "dt": dt, "flux": None, "batch": nv} for j in range(nv)]
+                 "n_dof": prob.n, "dt": dt, "flux": fluxes[j], "batch": nv} for j in range(nv)]
 
     def run(self, cfg, stack, watcher_points=None, field_sink=None, read_flux=False, two_sided=False):
         """One simulation (reference loop run_with_diamond.py:456-504).  Returns a dict with
@@ -408,6 +424,13 @@ class FluxSampler:
         # the only nodes whose gradient is ever read: band groups first, axis nodes last (hf_flux_sample order)
         self.nodes = np.concatenate(self.groups + [self.axis_nodes]).astype(np.int32) if self.groups else self.axis_nodes.astype(np.int32)
         self._cuts = np.cumsum([len(g) for g in self.groups])
+
+    def clone(self):
+        """An empty sampler of the same mesh (the node groups are shared, the recorded rows are not)."""
+        import copy as _copy
+        c = _copy.copy(self)
+        c.times, c.rows, c.raw_rows = [], [], []
+        return c
 
     def record(self, t, grad_r):
         """grad_r: the full nodal field."""
@@ -545,23 +568,30 @@ def run_simulation_impl(kind, cfg, mesh_folder, rebuild_mesh=False, visualize_me
         return result
 
 
-def run_simulation_batch_impl(kind, cfgs, output_folders, watcher_points_list, session, suppress_print=True):
+def run_simulation_batch_impl(kind, cfgs, output_folders, watcher_points_list, session, suppress_print=True, read_flux=False):
     """``run_simulation`` for 2, 4, 8 or 16 configurations of one resident mesh at once (SimulationSession.run_batch):
-    the same per-run artefacts (``used_config.yaml``, ``watcher_points.csv``) in each output folder, no XDMF,
-    no read-flux projection.  Returns the list of result dicts."""
+    the same per-run artefacts (``used_config.yaml``, ``watcher_points.csv``, with ``read_flux`` also run_no_diamond's
+    ``radial_gradient.csv`` / ``radial_gradient_raw.csv``) in each output folder, no XDMF.  The columns of a batch are
+    sampled at the same nodes: all configurations must name the same watcher points (``ValueError`` otherwise - the
+    points of a sweep group share their geometry and therefore do).  Returns the list of result dicts."""
     with suppress_output(suppress_print):
         t0 = time.time()
         stacks = [stack_with_diamond(c) if kind == "with_diamond" else stack_no_diamond(c) for c in cfgs]
-        for wp in watcher_points_list:
-            _parse_watchers(wp)
+        parsed = [_parse_watchers(wp) for wp in watcher_points_list]
+        for names_j, coords_j in parsed[1:]:
+            if names_j != parsed[0][0] or not np.array_equal(np.asarray(coords_j, dtype=float), np.asarray(parsed[0][1], dtype=float)):
+                raise ValueError("run_simulation_batch_impl: the configurations of a batch must share their watcher points "
+                                 "(one set of sample nodes serves every column)")
         for cfg, folder in zip(cfgs, output_folders):
             os.makedirs(folder, exist_ok=True)
             with open(os.path.join(folder, "used_config.yaml"), "w") as f:
                 _dump_yaml(cfg, f)
-        results = session.run_batch(cfgs, stacks, watcher_points_list[0])
+        results = session.run_batch(cfgs, stacks, watcher_points_list[0], read_flux=read_flux and kind == "no_diamond")
         for res, folder, wp in zip(results, output_folders, watcher_points_list):
             if wp is not None:
                 write_watcher_csv(os.path.join(folder, "watcher_points.csv"), res["times"], res["watcher_names"], res["watchers"])
+            if res.get("flux") is not None:
+                res["flux"].write(folder)
             res["save_folder"] = folder
             res["total_time"] = (time.time() - t0) / len(cfgs)
         return results

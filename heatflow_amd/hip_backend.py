@@ -24,7 +24,7 @@ EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_mesh_prebuilt", "hf_pattern_export_size",
     "hf_pattern_export", "hf_set_materials",
     "hf_update_kappa", "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_set_start_vector", "hf_get_response_solves", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
-    "hf_batch_begin", "hf_batch_load_column", "hf_batch_set_affine", "hf_batch_set_state", "hf_batch_get_state", "hf_batch_run", "hf_batch_end",
+    "hf_batch_begin", "hf_batch_load_column", "hf_batch_set_affine", "hf_batch_set_state", "hf_batch_get_state", "hf_batch_run", "hf_batch_run_flux", "hf_batch_end",
     "hf_flux_setup", "hf_flux_project", "hf_flux_solve", "hf_flux_sample", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
 ]
 
@@ -108,6 +108,7 @@ def load_library():
         "hf_batch_set_state": [vp, i32, pd],
         "hf_batch_get_state": [vp, i32, pd],
         "hf_batch_run": [vp, i32, pd, dbl, dbl, i32, i32, pi, pd, pi],
+        "hf_batch_run_flux": [vp, i32, pd, dbl, dbl, i32, i32, pi, pd, pi, i32, dbl, i32, i32, pi, pd, pi],
         "hf_batch_end": [vp],
         "hf_flux_setup": [vp],
         "hf_flux_project": [vp, dbl, i32, pd, pd, pi],
@@ -348,8 +349,12 @@ class HeatflowHIP:
         self._check(self._lib.hf_batch_get_state(self._ctx, int(j), _pd(u)))
         return u
 
-    def batch_run(self, g_all, rtol=1e-10, atol=0.0, max_it=20000, nodes=None):
-        """g_all: (n_steps, n_bc, nv).  Returns samples (n_steps, nv, n_s) and iters (n_steps, nv)."""
+    def batch_run(self, g_all, rtol=1e-10, atol=0.0, max_it=20000, nodes=None, flux_nodes=None, flux_components=2,
+                  flux_rtol=None, flux_max_it=5000):
+        """g_all: (n_steps, n_bc, nv).  Returns samples (n_steps, nv, n_s) and iters (n_steps, nv).
+        With ``flux_nodes`` every step is followed by the read-flux projection of every column (flux_setup() first;
+        ``flux_components``: 1 = d/dz, 2 = d/dr, 3 = both) and a third array is returned: the projected gradient at those
+        nodes, (n_steps, n_comp, nv, len(flux_nodes)), z before r."""
         g = _f64(g_all)
         if g.ndim != 3 or g.shape[1] != self.n_bc or (self.batch_nv and g.shape[2] != self.batch_nv):
             raise ValueError(f"batch_run: g_all must be (n_steps, {self.n_bc}, {self.batch_nv or 'nv'})")
@@ -359,11 +364,23 @@ class HeatflowHIP:
         ns = 0 if idx is None else len(idx)
         samples = np.empty((nsteps, nv, ns), dtype=np.float64)
         iters = np.zeros((nsteps, nv), dtype=np.int32)
-        rc = self._lib.hf_batch_run(self._ctx, nsteps, _pd(g) if self.n_bc else None, rtol, atol, int(max_it), ns, _pi(idx),
-                                    _pd(samples) if ns else None, _pi(iters))
-        self.last_run_iters = iters
+        if flux_nodes is None:
+            rc = self._lib.hf_batch_run(self._ctx, nsteps, _pd(g) if self.n_bc else None, rtol, atol, int(max_it), ns, _pi(idx),
+                                        _pd(samples) if ns else None, _pi(iters))
+            self.last_run_iters = iters
+            self._check(rc)
+            return samples, iters
+        fidx = _i32(flux_nodes)
+        comps = int(flux_components)
+        ncomp = (comps & 1) + ((comps >> 1) & 1)
+        flux = np.empty((nsteps, ncomp, nv, len(fidx)), dtype=np.float64)
+        fit = np.zeros((nsteps, max(ncomp, 1)), dtype=np.int32)
+        rc = self._lib.hf_batch_run_flux(self._ctx, nsteps, _pd(g) if self.n_bc else None, rtol, atol, int(max_it), ns, _pi(idx),
+                                         _pd(samples) if ns else None, _pi(iters), comps, float(rtol if flux_rtol is None else flux_rtol),
+                                         int(flux_max_it), len(fidx), _pi(fidx), _pd(flux), _pi(fit))
+        self.last_run_iters, self.last_flux_iters = iters, fit
         self._check(rc)
-        return samples, iters
+        return samples, iters, flux
 
     def batch_end(self):
         self._check(self._lib.hf_batch_end(self._ctx))

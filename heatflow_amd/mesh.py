@@ -394,14 +394,20 @@ class Mesh:
     def write(self, filename: str, version: str = "2.2"):
         """Write the mesh.  ``*.msh`` -> Gmsh ASCII, MSH 2.2 (default, native writer) or MSH 4.1 (the
         format the reference's ``gmsh.write`` produces, mesh.py:191-195); both are readable by gmsh and
-        by :func:`read_msh`.  A binary ``.npz`` sidecar is written beside it for fast reload."""
+        by :func:`read_msh`.  Beside a 2.2 file, which lists nodes and triangles in this mesh's own order, a binary
+        ``.npz`` sidecar is written for fast reload (:func:`load_mesh_arrays`); a 4.1 file groups its elements by
+        surface, so no sidecar goes with it (a stale one is removed): every reload of that file goes through
+        :func:`read_msh` and sees one element numbering."""
         if self.coords is None:
             raise RuntimeError("Mesh not built - call build_mesh() first.")
+        side = os.path.splitext(filename)[0] + ".npz"
         if str(version).startswith("4"):
             write_msh41(filename, self.coords, self.tris, self.tags, self.material_tags)
+            if os.path.isfile(side):
+                os.remove(side)
         else:
             write_msh(filename, self.coords, self.tris, self.tags, self.material_tags)
-        np.savez(os.path.splitext(filename)[0] + ".npz", coords=self.coords, tris=self.tris, tags=self.tags)
+            np.savez(side, coords=self.coords, tris=self.tris, tags=self.tags)
 
 
 def write_msh(filename, coords, tris, tags, names=None):

@@ -30,8 +30,25 @@ from datetime import datetime
 import numpy as np
 import yaml
 
+import sys
+
 from .driver import SimulationSession, build_pattern_blob, prepare_mesh, run_simulation_batch_impl, run_simulation_impl
 from .geometry import build_stack, watcher_points as _watcher_points
+from .hip_backend import HipError, NotConverged
+
+
+def batch_failure(e, n_points):
+    """What to do when a batched time loop raised ``e``.  Returns ``(retry_singly, text)``: a batch that did not converge
+    as a whole (``NotConverged``: one hard column stops all of them) or that the configurations do not admit
+    (``ValueError``) is re-run point by point, and ``text`` goes into every such row as ``batch_error`` and to stderr - a
+    batch that always fails must show in the rows, not only as a slow sweep.  Anything else (a HIP error, an allocation
+    failure, a bug) is not retried: the device or the session is suspect, the points become failed rows (reference:
+    parameter_sweep.py:154-192, every exception becomes a ``status='failed'`` row, :516-518 ``failed_runs.csv``)."""
+    text = f"{type(e).__name__}: {e}"
+    retry = isinstance(e, (NotConverged, ValueError)) or (isinstance(e, HipError) and getattr(e, "code", None) == -4)
+    print(f"heatflow_amd.parameter_sweep: batched time loop of {n_points} points failed ({text}); "
+          + ("re-running them one by one" if retry else "not retried"), file=sys.stderr)
+    return retry, text
 
 
 def get_watcher_points(cfg):
@@ -213,13 +230,19 @@ def run_single_simulation(args, session=None, kind=None):
 
 def run_simulation_group(items, base_config, mesh_folder, output_dir, write_xdmf, suppress_print, session, kind):
     """``items`` = [(run_id, combo), ...]: two or more points advance together through the batched time loop
-    (same status rows as run_single_simulation); if the batch fails as a whole, or XDMF / read-flux output is
-    wanted, every point is run on its own instead."""
-    def singly():
-        return [run_single_simulation((combo, base_config, mesh_folder, output_dir, write_xdmf, suppress_print, run_id),
-                                      session=session, kind=kind) for run_id, combo in items]
+    (same status rows as run_single_simulation), run_no_diamond's per-step read-flux projection included; with XDMF
+    output every point is run on its own.  A batch that fails as a whole: see :func:`batch_failure`."""
+    def singly(batch_error=None):
+        out = []
+        for run_id, combo in items:
+            row = run_single_simulation((combo, base_config, mesh_folder, output_dir, write_xdmf, suppress_print, run_id),
+                                        session=session, kind=kind)
+            if batch_error is not None:
+                row["batch_error"] = batch_error
+            out.append(row)
+        return out
 
-    if len(items) == 1 or write_xdmf or kind == "no_diamond":     # run_no_diamond's per-step flux projection is not batched
+    if len(items) == 1 or write_xdmf:
         return singly()
     rows, cfgs, folders = [], [], []
     for run_id, combo in items:
@@ -231,13 +254,19 @@ def run_simulation_group(items, base_config, mesh_folder, output_dir, write_xdmf
                      "runtime": 0.0, "status": "failed", "error": None})
     try:
         t0 = time.time()
-        results = run_simulation_batch_impl(kind, cfgs, folders, [get_watcher_points(c) for c in cfgs], session, suppress_print)
+        results = run_simulation_batch_impl(kind, cfgs, folders, [get_watcher_points(c) for c in cfgs], session, suppress_print,
+                                            read_flux=(kind == "no_diamond"))
         for row, res in zip(rows, results):
             row.update(runtime=(time.time() - t0) / len(items), status="success", pcg_iters_mean=float(np.mean(res["iters"])),
                        pcg_iters_max=int(np.max(res["iters"])), batch=len(items))
         return rows
-    except Exception:
-        return singly()
+    except Exception as e:  # noqa: BLE001 - classified by batch_failure, never swallowed
+        retry, text = batch_failure(e, len(items))
+        if retry:
+            return singly(batch_error=text)
+        for row in rows:
+            row.update(error=f"batched time loop failed: {text}", batch_error=text)
+        return rows
 
 
 def run_parameter_sweep(base_config_path, output_dir, fwhm_range, k_range, width_range, num_points,
@@ -322,6 +351,8 @@ def _write_rows(path, rows):
     import csv
 
     keys = list(rows[0].keys())
+    for r in rows[1:]:                      # rows of a sweep may carry extra fields (batch, batch_error): keep every column
+        keys += [k for k in r.keys() if k not in keys]
     with open(path, "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=keys, extrasaction="ignore")
         w.writeheader()
@@ -418,8 +449,12 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
         try:
             results = run_simulation_batch_impl(stack.kind, cfgs, [os.path.join(output_dir, f"{k:.{digits}f}") for k in ks],
                                                 [get_watcher_points(c) for c in cfgs], sess, True)
-        except Exception:
-            return [one_point(k, sess) for k in ks]
+        except Exception as e:  # noqa: BLE001 - classified by batch_failure, never swallowed
+            retry, text = batch_failure(e, len(ks))
+            if retry:
+                return [dict(one_point(k, sess), batch_error=text) for k in ks]
+            return [{"k": float(k), "rmse": float("nan"), "runtime": 0.0, "status": "failed", "rank": rank,
+                     "error": f"batched time loop failed: {text}", "batch_error": text} for k in ks]
         rows_ = []
         for k, c, res in zip(ks, cfgs, results):
             row = {"k": float(k), "rmse": float("nan"), "runtime": (time.time() - t0) / len(ks), "status": "success", "error": None,

@@ -199,6 +199,17 @@ int hf_batch_set_state(hf_ctx* ctx, int32_t j, const double* u);
 int hf_batch_get_state(hf_ctx* ctx, int32_t j, double* u);
 int hf_batch_run(hf_ctx* ctx, int32_t n_steps, const double* g_bc_all, double rtol, double atol, int32_t max_it,
                  int32_t n_s, const int32_t* nodes, double* samples, int32_t* iters);
+/* hf_batch_run with run_no_diamond's per-step read-flux projection for every column (reference run_no_diamond.py:543-566,
+ * which the sweep of parameter_sweep.py:43,157-166 runs at every grid point): after each step the gradient of each column's
+ * new state is L2-projected with the r-weighted unit mass matrix (hf_flux_setup first) - per wanted component (bit 0 = z,
+ * bit 1 = r; the reference's outputs read d/dr only) the nv columns are the interleaved columns of ONE Jacobi-PCG,
+ * warm-started from the previous step's projection, stopping rule of hf_step with flux_rtol - and sampled at n_fs nodes:
+ * flux_samples = n_steps x n_comp x nv x n_fs ([step][component, z before r][column][node]); flux_iters = n_steps x n_comp
+ * (largest count among the columns; may be NULL).  flux_components = 0 is hf_batch_run. */
+int hf_batch_run_flux(hf_ctx* ctx, int32_t n_steps, const double* g_bc_all, double rtol, double atol, int32_t max_it,
+                      int32_t n_s, const int32_t* nodes, double* samples, int32_t* iters, int32_t flux_components,
+                      double flux_rtol, int32_t flux_max_it, int32_t n_fs, const int32_t* flux_nodes, double* flux_samples,
+                      int32_t* flux_iters);
 int hf_batch_end(hf_ctx* ctx);
 
 /* Read-flux projection of run_no_diamond (reference run_no_diamond.py:471-491 set-up, :543-550 per

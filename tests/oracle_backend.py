@@ -114,9 +114,12 @@ class OracleBackend:
     def batch_get_state(self, j):
         return self._bcols[j]["u"].copy()
 
-    def batch_run(self, g_all, rtol=1e-10, atol=0.0, max_it=20000, nodes=None):
+    def batch_run(self, g_all, rtol=1e-10, atol=0.0, max_it=20000, nodes=None, flux_nodes=None, flux_components=2,
+                  flux_rtol=None, flux_max_it=5000):
         nsteps, _, nv = g_all.shape
         ns = 0 if nodes is None else len(nodes)
+        comps = [c for c in (0, 1) if (int(flux_components) >> c) & 1]
+        flux = None if flux_nodes is None else np.empty((nsteps, len(comps), nv, len(flux_nodes)))
         samples = np.empty((nsteps, nv, ns))
         for s in range(nsteps):
             for j, col in enumerate(self._bcols):
@@ -128,6 +131,13 @@ class OracleBackend:
                 col["u"] = col["lu"].solve(b)
                 if ns:
                     samples[s, j] = col["u"][np.asarray(nodes)]
+                if flux is not None:
+                    g2 = self._proj.project(col["u"])[np.asarray(flux_nodes)]
+                    for q, c in enumerate(comps):
+                        flux[s, q, j] = g2[:, c]
+        self.batch_flux_calls = getattr(self, "batch_flux_calls", 0) + (flux is not None)
+        if flux is not None:
+            return samples, np.ones((nsteps, nv), dtype=np.int32), flux
         return samples, np.ones((nsteps, nv), dtype=np.int32)
 
     def batch_end(self):

@@ -568,7 +568,7 @@ def test_two_triangle_mesh_and_context_reuse(hip):
 
 def test_two_contexts_on_two_threads_agree_with_sequential(hip, case_with_diamond_small):
     """Contexts are independent (own stream, stream-ordered copies only): two of them stepped from two
-    host threads at once - with hipGraph capture happening in both - give the sequential results."""
+    host threads at once - each polling its own progress mirror - give the sequential results."""
     import threading
 
     cfg, stack, mesh = case_with_diamond_small
@@ -894,6 +894,51 @@ def test_polled_and_copied_back_loops_give_identical_results(hip, tmp_path):
     for key in ("u", "it", "ub", "bit"):
         assert np.array_equal(out["1"][key], out["0"][key]), key
     assert out["1"]["it"].max() >= 5 and out["1"]["bit"].max() >= 3
+
+
+@pytest.mark.gpu
+def test_batched_polled_loop_after_a_hard_solve_followed_by_easy_ones(hip, tmp_path):
+    """The polled batched loop queues a blind first burst of (previous iteration count - 2) iterations.  When the next
+    solves need far fewer (here: the same steps again at a much looser tolerance), the rest of the burst is still queued
+    when the host moves on to the next step; whatever those launches publish must not be taken for progress of the new
+    solve (ScalMirror epochs; columns that have converged publish nothing).  On a mesh big enough that the device lags the
+    host, polled and copied-back loops must agree bit for bit in iteration counts and fields."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(os.path.join(ROOT, 'tests'))!r})\n"
+        "from conftest import build_case\n"
+        "from helpers import make_problem\n"
+        "from heatflow_amd import hip_backend as hb\n"
+        "cfg, stack, mesh = build_case('geballe_with_diamond', 1.0)\n"
+        "prob = make_problem(cfg, stack, mesh, precond=1, amg_reuse=True)\n"
+        "be = prob.backend\n"
+        "nv = 8\n"
+        "be.batch_begin(nv, hb.BATCH_SHARED)\n"
+        "g = np.stack([np.repeat(prob.bc_values((s + 1) * prob.dt, [prob.bcs[3]])[:, None], nv, axis=1) + 3.0 * np.arange(nv) for s in range(8, 40, 4)])\n"
+        "for j in range(nv): be.batch_set_state(j, np.full(prob.n, 300.0 + j))\n"
+        "its = []\n"
+        "for rtol in (1e-12, 1e-3, 1e-12, 1e-2, 1e-3):\n"
+        "    _, bit = be.batch_run(g, rtol, 0.0, prob.max_it, None)\n"
+        "    its.append(np.array(bit))\n"
+        "ub = np.stack([be.batch_get_state(j) for j in range(nv)])\n"
+        "be.batch_end()\n"
+        "np.savez(sys.argv[1], ub=ub, bit=np.concatenate(its))\n"
+        "prob.close()\n")
+    out = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, HEATFLOW_POLL=flag)
+        res = subprocess.run([sys.executable, str(script), str(tmp_path / f"o{flag}.npz")], env=env, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out[flag] = np.load(tmp_path / f"o{flag}.npz")
+    bit = out["1"]["bit"]
+    assert np.array_equal(bit, out["0"]["bit"])
+    assert np.array_equal(out["1"]["ub"], out["0"]["ub"])
+    per_call = bit.reshape(5, -1, 8).max(axis=(1, 2))
+    assert per_call[0] >= per_call[1] + 3 and per_call[2] >= per_call[3] + 3, per_call     # the drops that leave launches queued
 
 
 def test_two_heated_lines_take_two_response_directions(hip, case_no_diamond_small):

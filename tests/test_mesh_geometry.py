@@ -322,9 +322,21 @@ def test_msh41_writer_round_trip_keeps_physical_tags(tmp_path):
     coords, tris, tags = read_msh(path)
     assert coords.shape == mesh.coords.shape and tris.shape == mesh.tris.shape
     assert np.array_equal(_tri_key(coords, tris, tags), _tri_key(mesh.coords, mesh.tris, mesh.tags))   # bit-exact (%.17g)
-    # Mesh.write(version="4.1") goes the same way and keeps the npz sidecar
+    # Mesh.write: a 2.2 file keeps this mesh's node and element order, so its npz sidecar and a read of the file agree
+    # element by element; a 4.1 file groups elements by surface and therefore carries no sidecar (and removes a stale one):
+    # both reload paths of one file always see one numbering
+    from heatflow_amd.mesh import load_mesh_arrays
     p2 = str(tmp_path / "mesh.msh")
+    mesh.write(p2)
+    assert (tmp_path / "mesh.npz").is_file()
+    c2, t2, g2 = read_msh(p2)
+    cs, ts, gs = load_mesh_arrays(p2)
+    assert np.array_equal(c2, cs) and np.array_equal(t2, ts) and np.array_equal(g2, gs)
     mesh.write(p2, version="4.1")
+    assert not (tmp_path / "mesh.npz").exists()
     c2, t2, g2 = read_msh(p2)
     assert np.array_equal(_tri_key(c2, t2, g2), _tri_key(mesh.coords, mesh.tris, mesh.tags))
-    assert (tmp_path / "mesh.npz").is_file()
+    ca, ta, ga = load_mesh_arrays(p2)
+    cb, tb, gb = load_mesh_arrays(p2)
+    assert np.array_equal(ta, tb) and np.array_equal(ga, gb) and np.array_equal(ca, cb)
+    assert np.array_equal(_tri_key(ca, ta, ga), _tri_key(mesh.coords, mesh.tris, mesh.tags))
