@@ -361,6 +361,45 @@ __global__ __launch_bounds__(KB_BT) void kb_spmv_lds(int n, const int32_t* __res
   }
 }
 
+// Generic CSR operator (shared values) times NV interleaved columns, thread = (entry lane, column): EL * NV threads
+// share a row, thread (e, j) adds the row's entries k = e (mod EL) for column j - one accumulator per thread, the index
+// and value loads are broadcasts among the NV column lanes, the operand and result accesses NV contiguous doubles -
+// and the EL partial sums are combined by log2(EL) shuffles.  For operators of many rows (the level-1 up leg of the stock
+// mesh: 30 k rows of 23 entries, 16 -> 11 us): kb_csr below spends NV * log2(lanes) shuffles per row, this kernel
+// log2(EL); for the few long rows of the coarser levels kb_csr's shorter dependent-load chain wins (measured).
+// VMODE 0: y = A x, 1: y += A x.
+template <int NV, int EL, int VMODE, typename VT>
+__global__ __launch_bounds__(TPB) void kb_csr_rc(int nrow, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                              const VT* __restrict__ val, const double* __restrict__ x, double* __restrict__ y) {
+  constexpr int TPR = EL * NV;                 // threads per row: a power of two <= 64
+  static_assert(TPR <= 64 && (TPR & (TPR - 1)) == 0, "threads per row");
+  const int j = threadIdx.x % NV, e = (threadIdx.x / NV) % EL;
+  const int rows_per_pass = (gridDim.x * TPB) / TPR;
+  for (int row = (blockIdx.x * TPB + threadIdx.x) / TPR; row < nrow; row += rows_per_pass) {
+    const int k1 = ptr[row + 1];
+    const size_t o = static_cast<size_t>(row) * NV + j;
+    const double y0 = (VMODE == 1 && e == 0) ? y[o] : 0.0;
+    double s = 0.0;
+    for (int k = ptr[row] + e; k < k1; k += 4 * EL) {
+      int c[4];
+      double v[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = k + u * EL < k1;
+        c[u] = in ? idx[k + u * EL] : 0;
+        v[u] = in ? static_cast<double>(val[k + u * EL]) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = (k + u * EL < k1) ? x[static_cast<size_t>(c[u]) * NV + j] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u] * xv[u];
+    }
+#pragma unroll
+    for (int q = EL / 2; q > 0; q >>= 1) s += __shfl_down(s, q * NV, TPR);
+    if (e == 0) y[o] = (VMODE == 1) ? y0 + s : s;
+  }
+}
+
 // Generic CSR operator (shared values) times NV interleaved columns: LANES lanes share a row, each keeps NV
 // accumulators, so every index and value is read once.  VMODE 0: y = A x, 1: y += A x.
 template <int NV, int LANES, int VMODE, typename VT>
@@ -679,10 +718,12 @@ size_t batch_lds_bytes(int cap_nnz, int cap_dict, int nv, bool affine) {
   return (static_cast<size_t>(affine ? 2 : 1) * cap_nnz + static_cast<size_t>(cap_dict) * nv) * 8 + ((static_cast<size_t>(cap_nnz) * 2 + 7) & ~static_cast<size_t>(7));
 }
 
-// Tables of kb_spmv_lds for `nv` columns.  Rows per chunk: a multiple of the rows one pass of the workgroup covers
-// (KB_BT / nv), as many as make the launch about one round of resident workgroups (<= MAXP chunks where the mesh allows it,
-// at most 4 passes), fewer if the chunk's operands would not fit the 64-KB LDS window of a launch.  HEATFLOW_BATCH_LDS=0
-// keeps the gather kernel (A/B); HEATFLOW_BATCH_RPC overrides the rows per chunk.
+// Tables of kb_spmv_lds for `nv` columns.  Rows per chunk: two passes of the workgroup (2 * KB_BT / nv rows: 128 for 8
+// columns), one on meshes too small to give every workgroup a chunk that way; fewer if the chunk's operands would not
+// fit the 64-KB LDS window of a launch.  Measured on the stock mesh (191 k rows, 8 columns, one batched multigrid-PCG
+// iteration): 64 / 128 / 192 / 256 rows per chunk -> 140 / 141 / 152 / 157 us - small chunks keep four workgroups per
+// CU resident (30 KB of LDS each) and their staging overlaps other workgroups' products.  HEATFLOW_BATCH_LDS=0 keeps
+// the gather kernel (A/B); HEATFLOW_BATCH_RPC overrides the rows per chunk.
 int ensure_batch_cols(hf_ctx* ctx, int nv) {
   static const bool enabled = !(std::getenv("HEATFLOW_BATCH_LDS") && std::getenv("HEATFLOW_BATCH_LDS")[0] == '0');
   hf_ctx::BatchCols& T = ctx->bcols;
@@ -690,7 +731,7 @@ int ensure_batch_cols(hf_ctx* ctx, int nv) {
   if (T.nv == nv) return HF_OK;
   free_batch_cols(ctx);
   const int rpp = KB_BT / nv;
-  int m = static_cast<int>(std::min<long long>(4, std::max<long long>(1, (static_cast<long long>(ctx->n) + static_cast<long long>(rpp) * MAXP - 1) / (static_cast<long long>(rpp) * MAXP))));
+  int m = static_cast<long long>(ctx->n) >= static_cast<long long>(rpp) * MAXP ? 2 : 1;
   if (const char* e = std::getenv("HEATFLOW_BATCH_RPC")) m = std::max(1, std::atoi(e) / rpp);
   for (; m >= 1; --m) {
     const int rpc = m * rpp;
@@ -734,7 +775,32 @@ int ensure_batch_cols(hf_ctx* ctx, int nv) {
 template <int NV, int VMODE, typename VT>
 void blaunch_csr_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y) {
   const double avg = m.nrow ? static_cast<double>(m.nnz) / m.nrow : 1.0;
-  const int lanes = avg <= 2.5 ? 2 : avg <= 5.0 ? 4 : avg <= 10.0 ? 8 : avg <= 20.0 ? 16 : avg <= 40.0 ? 32 : 64;
+  // operators of many rows (>= HEATFLOW_BATCH_RC_ROWS, default 16384) with rows long enough to share: thread = (entry lane, column)
+  static const int rc_rows = std::getenv("HEATFLOW_BATCH_RC_ROWS") ? std::atoi(std::getenv("HEATFLOW_BATCH_RC_ROWS")) : 16384;
+  static const double rc_per_thread = std::getenv("HEATFLOW_BATCH_RC_PER_THREAD") ? std::atof(std::getenv("HEATFLOW_BATCH_RC_PER_THREAD")) : 6.0;
+  static const double rc_min_avg = std::getenv("HEATFLOW_BATCH_RC_MIN_AVG") ? std::atof(std::getenv("HEATFLOW_BATCH_RC_MIN_AVG")) : 20.0;
+  if (m.nrow >= rc_rows && avg >= rc_min_avg) {
+    constexpr int ELMAX = 64 / NV;
+    int el = 1;
+    while (el < ELMAX && avg > rc_per_thread * el) el *= 2;
+    const long long threads = static_cast<long long>(m.nrow) * el * NV;
+    const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 4096)));
+#define HF_BCSR(L) hipLaunchKernelGGL((kb_csr_rc<NV, (L <= ELMAX ? L : ELMAX), VMODE, VT>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, val, x, y)
+    switch (el) {
+      case 1: HF_BCSR(1); break;
+      case 2: HF_BCSR(2); break;
+      case 4: HF_BCSR(4); break;
+      case 8: HF_BCSR(8); break;
+      case 16: HF_BCSR(16); break;
+      default: HF_BCSR(32); break;
+    }
+#undef HF_BCSR
+    return;
+  }
+  // lanes per row: the smallest power of two that leaves a lane about HEATFLOW_BATCH_CSR_PER_LANE (default 1.25) entries
+  static const double per_lane = std::getenv("HEATFLOW_BATCH_CSR_PER_LANE") ? std::atof(std::getenv("HEATFLOW_BATCH_CSR_PER_LANE")) : 1.25;
+  int lanes = 2;
+  while (lanes < 64 && avg > per_lane * lanes) lanes *= 2;
   const long long threads = static_cast<long long>(m.nrow) * lanes;
   const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 4096)));
 #define HF_BCSR(L) hipLaunchKernelGGL((kb_csr<NV, L, VMODE, VT>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, val, x, y)
