@@ -33,8 +33,12 @@ refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
 * cpu_baseline: the oracle (reference algorithm: assemble once, sparse LU once, two
   triangular solves per step; SciPy SuperLU, 1 thread) on the same mesh, rank 0, N = 1 only.
 * C5's CPU baseline (``cpu_baseline`` of workload sweep64, ``config.sweep64.cpu_farm_baseline`` of the default one):
-  8 of the 64 points through the oracle on a pool of one single-threaded process per point, as the reference farms
-  its points over ``mp.Pool`` (parameter_sweep.py:423-446).  It runs in a child process before this one touches the GPU.
+  ALL 64 points through the oracle on a pool of single-threaded processes, one per core up to 64, as the reference farms
+  its points over ``mp.Pool(processes=mp.cpu_count())`` (parameter_sweep.py:389-390, 423-446); the round-2 figure (8 points
+  on 8 cores) is kept beside it (``cpu_farm_8_points``).  Both run in child processes before this one touches the GPU.
+* roofline of workload sweep64 (``config.sweep64.roofline`` of the default one): the batched loop's iteration head
+  kb_spmv_lds<9> (8 columns, affine operator family), in-loop events on one batch of 8 at stock size, and the same kernel
+  on the 1M-DOF mesh, where the batch's vectors (66 MB each) are far beyond the Infinity Cache (``hbm_resident``).
 """
 import os
 
@@ -84,9 +88,12 @@ def parse_args(argv=None):
                     help="sweep points advanced together by the batched time loop (16, 8, 4, 2; 1 = one run per point)")
     ap.add_argument("--hbm-scale", type=float, default=HBM_SCALE,
                     help="mesh factor of the HBM-resident roofline point (N = 1 only; 0 = skip)")
-    ap.add_argument("--cpu-farm-points", type=int, default=8,
-                    help="C5 CPU baseline (N = 1 only): this many sweep points through the reference algorithm, one process per point "
-                         "(mirrors the reference's mp.Pool, parameter_sweep.py:423-446); 0 = skip.  Runs before anything touches the GPU")
+    ap.add_argument("--cpu-farm-points", type=int, default=SWEEP_POINTS,
+                    help="C5 CPU baseline (N = 1 only): this many sweep points through the reference algorithm on a pool of single-threaded "
+                         "processes, one per usable core up to this many (mirrors the reference's mp.Pool(processes=mp.cpu_count()), "
+                         "parameter_sweep.py:389-390, 423-446); 0 = skip.  Runs before anything touches the GPU")
+    ap.add_argument("--cpu-farm-procs", type=int, default=0, help="processes of that pool (0 = min(points, usable cores))")
+    ap.add_argument("--batch-roofline", type=int, default=1, help="N = 1: roofline of the batched iteration head (0 = skip)")
     ap.add_argument("--cpu-farm-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="form the process group, report its size and exit: checks the launcher plumbing (no GPU work)")
@@ -191,7 +198,7 @@ def _farm_point(job):
     return time.perf_counter() - t0
 
 
-def cpu_farm_worker(n_points, steps_per_point):
+def cpu_farm_worker(n_points, steps_per_point, max_procs=0):
     """Body of `bench.py --cpu-farm-worker` (a process of its own, started before the parent touches the GPU): mesh once,
     then `n_points` kappa_sample points of BASELINE C5 on a pool of one process per point (at most the box's cores)."""
     import multiprocessing as mp
@@ -211,7 +218,8 @@ def cpu_farm_worker(n_points, steps_per_point):
     mesh = Mesh("mesh.msh", stack.bounds, stack.materials).build_mesh()
     arrays, mtags = (mesh.coords, mesh.tris, mesh.tags), mesh.material_tags
     ks = ps.get_k_values(count=64)[:n_points]
-    procs = max(1, min(n_points, os.cpu_count() or 1))
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = max(1, min(n_points, max_procs if max_procs > 0 else usable))
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(procs) as pool:
         per_point = pool.map(_farm_point, [(cfg, k, arrays, mtags) for k in ks], chunksize=1)
@@ -220,21 +228,117 @@ def cpu_farm_worker(n_points, steps_per_point):
     print(json.dumps({
         "value": n_points * n * steps_per_point / wall, "unit": "DOF-updates/s", "cores": procs, "kind": "port",
         "sample": (f"{n_points} of the 64 kappa_sample points of BASELINE C5 (stock mesh, {n} DOF, {steps_per_point} steps each) through "
-                   f"oracle/heat_oracle.py (SciPy SuperLU, not FEniCS/MUMPS), one single-threaded process per point on {procs} of "
-                   f"{os.cpu_count()} host cores, each assembling and factorising for its point as the reference's pool workers do "
-                   f"(parameter_sweep.py:123-192); mesh built once and handed over; process start-up included"),
-        "wall_s": wall, "per_point_s_mean": float(sum(per_point) / len(per_point)), "points": n_points}))
+                   f"oracle/heat_oracle.py (SciPy SuperLU, not FEniCS/MUMPS) on a pool of {procs} single-threaded processes "
+                   f"({usable} cores usable by this process, os.cpu_count() = {os.cpu_count()}), each assembling and factorising for its "
+                   f"point as the reference's pool workers do (parameter_sweep.py:123-192, pool of mp.cpu_count() processes :389-390); "
+                   f"mesh built once and handed over; process start-up included"),
+        "wall_s": wall, "per_point_s_mean": float(sum(per_point) / len(per_point)), "points": n_points,
+        "usable_cores": usable, "cpu_count": os.cpu_count()}))
     return 0
 
 
-def run_cpu_farm(args, steps_per_point=100):
-    """Start the farm as a child process and return its JSON (None when it fails: the baseline is a report, not a gate)."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-farm-worker", "--cpu-farm-points", str(args.cpu_farm_points), "--steps", str(steps_per_point)]
+def run_cpu_farm(args, steps_per_point=100, points=None, procs=None):
+    """Start the farm as a child process and return its JSON (an error entry when it fails: the baseline is a report, not a gate)."""
+    points = args.cpu_farm_points if points is None else points
+    procs = args.cpu_farm_procs if procs is None else procs
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-farm-worker", "--cpu-farm-points", str(points), "--cpu-farm-procs", str(procs),
+           "--steps", str(steps_per_point)]
     try:
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         return json.loads(p.stdout.decode().strip().splitlines()[-1])
     except Exception as e:          # noqa: BLE001 - reported in the JSON line
         return {"error": f"{type(e).__name__}: {e}"}
+
+
+SOLVER_TEXT = ("PCG preconditioned by a smoothed-aggregation multigrid V(1,1) cycle with damped-Jacobi smoothing; operator A, mass matrix, "
+               "all vectors, residual, dot products and the stopping rule in f64; the operators that act only inside the preconditioner "
+               "(transfer operators P / R, fused legs, dense inverse of the coarsest level) are stored in f32 and applied to f64 vectors "
+               "with f64 accumulation")
+PRECISION_TEXT = ("preconditioner operators below the fine level f32 (values only; vectors and accumulation f64); fine operator, "
+                  "vectors, residual, stopping rule f64: the converged answer is the f64 PCG answer (HEATFLOW_AMG_F32=0 stores them in f64)")
+
+
+def attach_farms(cfg_out, gpu_value, farm, farm8):
+    """CPU farm baselines of C5 and the GPU / farm ratios, each with the core count it ran on."""
+    if farm and "value" in farm:
+        cfg_out["gpu_over_cpu_farm"] = gpu_value / farm["value"]
+        cfg_out["gpu_over_cpu_farm_cores"] = farm.get("cores")
+    if farm8:
+        cfg_out["cpu_farm_8_points"] = farm8
+        if "value" in farm8:
+            cfg_out["gpu_over_cpu_farm_8_points"] = gpu_value / farm8["value"]
+
+
+def batch_head_roofline(dev_index, nv, profile_steps=8):
+    """Roofline of the batched loop's dominant kernel, the iteration head kb_spmv_lds<9, nv, affine> (the C5 sweep: nv
+    kappa_sample points as the columns of one multi-vector PCG).  In-loop: kernel-attached HIP events on its launches
+    inside the time loop of one batch (hf_set_profile), on the stock mesh (the C5 size; the batch's working set of
+    ~135 MB sits in the 256 MiB Infinity Cache) and on the 1M-DOF mesh of C3 (vectors of 66 MB each: HBM-resident).
+    Algorithmic bytes per launch, SURVEY 8d conventions (f64 values, i32 indices, every array once per pass):
+    (4 + 16)*nnz [column index + the two shared value arrays of the affine family] + 4*n [row pointers]
+    + 40*n*nv [per row and column: z 8, Ap and p read-modify-write 32]."""
+    import copy
+    import yaml
+    from heatflow_amd.driver import SimulationSession
+    from heatflow_amd.geometry import build_stack, scale_mesh_sizes, watcher_points
+    from heatflow_amd.mesh import Mesh
+    from heatflow_amd import parameter_sweep as ps
+
+    def one(scale, steps):
+        with open(os.path.join(ROOT, "cfgs", "geballe_with_diamond.yaml")) as f:
+            cfg = scale_mesh_sizes(yaml.safe_load(f), scale)
+        cfg["heating"]["file"] = os.path.join(ROOT, cfg["heating"]["file"])
+        dt0 = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
+        cfg["timing"]["num_steps"] = int(steps)
+        cfg["timing"]["t_final"] = dt0 * int(steps)
+        stack = build_stack(cfg)
+        mesh = Mesh("mesh.msh", stack.bounds, stack.materials).build_mesh()
+        sess = SimulationSession(mesh.coords, mesh.tris, mesh.tags, mesh.material_tags, device_id=dev_index)
+        try:
+            cfgs = []
+            for k in ps.get_k_values(count=64)[:nv]:
+                c = copy.deepcopy(cfg)
+                c["mats"]["p_sample"]["k"] = float(k)
+                cfgs.append(c)
+            stacks = [build_stack(c) for c in cfgs]
+            from heatflow_amd.driver import suppress_output
+            with suppress_output(True):
+                sess.run_batch(cfgs, stacks, watcher_points(cfgs[0]))          # set-up + warm caches
+                be = sess.problem.backend
+                be.set_profile(True)
+                res = sess.run_batch(cfgs, stacks, watcher_points(cfgs[0]))
+                ms_sum, cnt = be.get_profile()
+                be.set_profile(False)
+            n, nnz = be.n, be.nnz
+            byts = 20 * nnz + 4 * n + 40 * n * nv
+            us = 1e3 * ms_sum / cnt if cnt else None
+            return {"workload": f"one batch of {nv} kappa_sample points, cfgs/geballe_with_diamond.yaml, every mats.*.mesh x {scale}, steps 0..{steps - 1}",
+                    "n_dof": n, "nnz": nnz, "nv": nv, "bytes_per_launch": byts, "us_per_launch_in_loop_events": us, "in_loop_launches": int(cnt),
+                    "achieved": byts / (us * 1e-6) / 1e9 if us else None, "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us else None,
+                    "pcg_iters_per_step_mean": float(sum(float(r["iters"].mean()) for r in res) / len(res)),
+                    "batch_ms_per_step": 1e3 * res[0]["loop_time"] * nv / steps,
+                    "working_set_bytes_vectors": 9 * 8 * n * nv, "cache_resident": bool(20 * nnz + 9 * 8 * n * nv < 256 * 2**20)}
+        finally:
+            sess.close()
+
+    stock = one(1.0, 30)
+    big = one(MESH_SCALE, 10)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_batch_latest.json")) as f:
+            pmc = json.load(f)
+        if pmc["n"] == stock["n_dof"] and pmc["nnz"] == stock["nnz"] and pmc["nv"] == nv:
+            traffic = pmc["kernels"][f"kb_spmv_lds<9,nv{nv},op2>"]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"bound": "hbm", "achieved": stock["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stock["frac"], "traffic": traffic,
+            "kernel": f"kb_spmv_lds<9, {nv}, affine> (batched PCG iteration head: CSR SpMV on {nv} interleaved columns with the direction update fused; "
+                      "chunk operands staged in LDS, 16-bit column positions)",
+            "bytes_per_launch": stock["bytes_per_launch"], "us_per_launch": stock["us_per_launch_in_loop_events"],
+            "formula": "(4 + 16)*nnz + 4*n + 40*n*nv",
+            "timing": "in-loop: kernel-attached HIP events on the kb_spmv_lds<9> launches of one batch's time loop",
+            "traffic_note": "PMC (2*FETCH_SIZE + WRITE_SIZE)*1024 of profiles/pmc_traffic_batch_latest.json when collected on this matrix and nv",
+            "stock_size": stock, "hbm_resident": big}
 
 
 class Ranks:
@@ -325,6 +429,8 @@ def run_sweep64(ranks, n_points, steps_per_point, warmup_steps, concurrent, batc
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     wall = ranks.max_over_ranks(clock["all"])
+    whole = ranks.max_over_ranks(t_all)          # mesh + broadcasts + connectivity tables + multigrid set-up + warm-up + point loop, slowest rank
+    setup_max = ranks.max_over_ranks(t_all - clock["all"])
     if ranks.rank != 0:
         return None
     bad = [r for r in rows if r["status"] != "success"]
@@ -346,8 +452,11 @@ def run_sweep64(ranks, n_points, steps_per_point, warmup_steps, concurrent, batc
             "one_run_per_point": 12 * 7 + 44, "batched": (4 + 16) * 7 / max(batch, 1) + 44 if batch > 1 else 12 * 7 + 44},
         "wall_s": wall, "value": n_points * n_dof * steps_per_point / wall, "unit": "DOF-updates/s",
         "points_per_s": n_points / wall, "pcg_iters_per_step_mean": float(np.mean([r["pcg_iters_mean"] for r in rows])),
-        "rank0_phases_s": {k: timing.get(k) for k in ("mesh_s", "broadcast_s", "warmup_s", "points_s")},
-        "whole_call_s": t_all,
+        "rank0_phases_s": {k: timing.get(k) for k in ("mesh_s", "broadcast_s", "pattern_build_s", "pattern_broadcast_s", "session_s", "warmup_s", "points_s")},
+        "whole_call_s": whole, "setup_s_max_over_ranks": setup_max,
+        "value_whole_call": n_points * n_dof * steps_per_point / whole,
+        "value_whole_call_note": ("the same DOF-updates over the whole call of the slowest rank: mesh, broadcasts, connectivity tables, "
+                                  "multigrid set-up and the untimed warm-up steps included - what a user of the sweep waits for"),
     }
 
 
@@ -456,14 +565,17 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     if args.cpu_farm_worker:
-        return cpu_farm_worker(args.cpu_farm_points, args.steps or 100)
+        return cpu_farm_worker(args.cpu_farm_points, args.steps or 100, args.cpu_farm_procs)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args, argv)
     # C5's CPU baseline is a pool of processes: it runs to completion here, before this process touches the GPU
-    farm = None
+    farm = farm8 = None
     if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_farm_points > 0 and not args.rendezvous_only
             and (args.workload == "sweep64" or (args.sweep_points > 0 and args.cpu_steps > 0))):
-        farm = run_cpu_farm(args, args.steps if args.workload == "sweep64" else 100)
+        farm_steps = args.steps if args.workload == "sweep64" else 100
+        farm = run_cpu_farm(args, farm_steps)
+        if args.cpu_farm_points > 8:           # the round-2 figure beside it: 8 points on 8 cores
+            farm8 = run_cpu_farm(args, farm_steps, points=8, procs=8)
 
     # stdout carries exactly ONE line (the JSON): everything else - RCCL's version banner, library
     # chatter - is sent to stderr by pointing fd 1 at fd 2 until the result is written
@@ -496,12 +608,13 @@ def main(argv=None):
     if args.workload == "sweep64":
         sw = run_sweep64(ranks, SWEEP_POINTS, args.steps, args.warmup, args.sweep_concurrent, args.sweep_batch)
         if rank == 0:
+            roof = batch_head_roofline(dev_index, args.sweep_batch) if (world == 1 and args.batch_roofline and args.sweep_batch > 1) else None
             out = dict(common, metric="DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond", value=sw["value"],
                        ms_per_step=1e3 * sw["wall_s"] / args.steps, scaling="strong",
-                       config={"workload": sw["workload"], **{k: v for k, v in sw.items() if k not in ("workload", "value", "unit")}},
-                       roofline=None, cpu_baseline=farm)
-            if farm and "value" in farm:
-                out["config"]["gpu_over_cpu_farm"] = sw["value"] / farm["value"]
+                       config={"workload": sw["workload"], "solver": SOLVER_TEXT, "precision": PRECISION_TEXT,
+                               **{k: v for k, v in sw.items() if k not in ("workload", "value", "unit")}},
+                       roofline=roof, cpu_baseline=farm)
+            attach_farms(out["config"], sw["value"], farm, farm8)
             emit(out)
         ranks.close()
         return 0
@@ -588,6 +701,7 @@ def main(argv=None):
     # ---- side measurements: the C5 sweep (every N), the HBM-resident roofline point (N = 1)
     sweep = run_sweep64(ranks, args.sweep_points, 100, max(1, args.warmup), args.sweep_concurrent, args.sweep_batch) if args.sweep_points > 0 else None
     hbm = hbm_resident_point(args.hbm_scale, dev_index, 3) if (world == 1 and args.hbm_scale > 0) else None
+    batch_roof = batch_head_roofline(dev_index, args.sweep_batch) if (world == 1 and sweep is not None and args.batch_roofline and args.sweep_batch > 1) else None
 
     if rank == 0:
         out = dict(common, metric="DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond",
@@ -596,7 +710,7 @@ def main(argv=None):
             "workload": f"cfgs/geballe_with_diamond.yaml, every mats.*.mesh x {args.scale} (BASELINE C3, ~1M DOF), "
                         f"steps {args.warmup}..{args.warmup + args.steps - 1} of 100, dt=7.5e-8 s",
             "n_dof": n, "n_elem": ne, "nnz": nnz, "n_dirichlet": be.n_bc,
-            "solver": ("PCG + smoothed-aggregation multigrid V(1,1), damped-Jacobi smoothing" if precond else "Jacobi-PCG"),
+            "solver": (SOLVER_TEXT if precond else "Jacobi-PCG, everything in f64"),
             "pcg_rtol": prob.rtol, "pcg_iters_per_step_mean": float(np.mean(iters)), "pcg_iters_per_step_max": int(np.max(iters)),
             "points": "1 sweep point per GPU (kappa_sample = 3.8 + 0.02*rank)" if world > 1 else "1 run",
             "gpu_ms_per_step_events": gpu_ms / args.steps, "rank0_setup_s": setup_s}
@@ -630,14 +744,15 @@ def main(argv=None):
                 "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "us_kernels_back_to_back": k_us["spmv9_back_to_back"] + k_us["update_back_to_back"]}
         if precond == 1:
-            out["config"]["amg"] = amg_info
+            out["config"]["amg"] = dict(amg_info, precision=PRECISION_TEXT)
         if jacobi is not None:
             out["config"]["jacobi_pcg"] = jacobi
         if sweep is not None:
             if farm:
                 sweep["cpu_farm_baseline"] = farm
-                if "value" in farm:
-                    sweep["gpu_over_cpu_farm"] = sweep["value"] / farm["value"]
+            attach_farms(sweep, sweep["value"], farm, farm8)
+            if batch_roof is not None:
+                sweep["roofline"] = batch_roof
             out["config"]["sweep64"] = sweep
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, mesh, args.cpu_steps, args.warmup)

@@ -845,7 +845,8 @@ struct BatchOps {
 
   template <int MODE>
   static void spmv(hf_ctx* c, const double* vals, const double* x, double* y, double* part0 = nullptr, const double* bvec = nullptr,
-                   double* pvec = nullptr, double* part1 = nullptr, double* part2 = nullptr, double w = 0.0, int parity = 0) {
+                   double* pvec = nullptr, double* part1 = nullptr, double* part2 = nullptr, double w = 0.0, int parity = 0,
+                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* hf_set_profile: the launch carries its own start / stop events */) {
     hf_ctx::Batch& B = c->batch;
     if (B.lds && OPK != OP_PERCOL) {    // chunk operands staged in LDS, 16-bit column positions
       const hf_ctx::BatchCols& T = c->bcols;
@@ -859,8 +860,12 @@ struct BatchOps {
                            c->n, c->d_rowptr, m, x, y, B.scal, part0, bvec, c->d_dinv, pvec, part1, part2, w, B.red, parity, comp, B.Pb);
       } else {
         constexpr int OPL = OPK == OP_PERCOL ? OP_SHARED : OPK;     // (never instantiated for per-column values)
-        hipLaunchKernelGGL((kb_spmv_lds<MODE, NV, OPL>), dim3(grid), dim3(KB_BT), batch_lds_bytes(T.cap_nnz, T.cap_dict, NV, OPL == OP_AFFINE), c->stream,
-                           c->n, c->d_rowptr, Aop(c), x, y, B.scal, part0, bvec, Dinv(c), pvec, part1, part2, w, B.red, parity, comp, B.Pb);
+        if (ev0 != nullptr)
+          hipExtLaunchKernelGGL((kb_spmv_lds<MODE, NV, OPL>), dim3(grid), dim3(KB_BT), static_cast<std::uint32_t>(batch_lds_bytes(T.cap_nnz, T.cap_dict, NV, OPL == OP_AFFINE)),
+                                c->stream, ev0, ev1, 0u, c->n, c->d_rowptr, Aop(c), x, y, B.scal, part0, bvec, Dinv(c), pvec, part1, part2, w, B.red, parity, comp, B.Pb);
+        else
+          hipLaunchKernelGGL((kb_spmv_lds<MODE, NV, OPL>), dim3(grid), dim3(KB_BT), batch_lds_bytes(T.cap_nnz, T.cap_dict, NV, OPL == OP_AFFINE), c->stream,
+                             c->n, c->d_rowptr, Aop(c), x, y, B.scal, part0, bvec, Dinv(c), pvec, part1, part2, w, B.red, parity, comp, B.Pb);
       }
       return;
     }
@@ -870,6 +875,9 @@ struct BatchOps {
       m.v0 = c->d_M;
       hipLaunchKernelGGL((kb_spmv<MODE, NV, OP_SHARED>), dim3(B.Pb), dim3(KB_BT), 0, c->stream, c->n, c->d_rowptr, c->d_colidx, m, x, y,
                          B.scal, part0, bvec, c->d_dinv, pvec, part1, part2, w, B.red, parity);
+    } else if (ev0 != nullptr) {
+      hipExtLaunchKernelGGL((kb_spmv<MODE, NV, OPK>), dim3(B.Pb), dim3(KB_BT), 0u, c->stream, ev0, ev1, 0u, c->n, c->d_rowptr, c->d_colidx, Aop(c), x, y,
+                            B.scal, part0, bvec, Dinv(c), pvec, part1, part2, w, B.red, parity);
     } else {
       hipLaunchKernelGGL((kb_spmv<MODE, NV, OPK>), dim3(B.Pb), dim3(KB_BT), 0, c->stream, c->n, c->d_rowptr, c->d_colidx, Aop(c), x, y,
                          B.scal, part0, bvec, Dinv(c), pvec, part1, part2, w, B.red, parity);
@@ -919,8 +927,12 @@ struct BatchOps {
 
   static void iteration(hf_ctx* c, bool use_amg, int parity) {
     hf_ctx::Batch& B = c->batch;
+    // hf_set_profile: the iteration heads of a solve (its first PROF_PAIRS) carry event pairs, harvested when the solve ends
+    const bool timed = c->prof && c->prof_used < PROF_PAIRS;
+    hipEvent_t e0 = timed ? c->prof_ev[2 * c->prof_used] : nullptr, e1 = timed ? c->prof_ev[2 * c->prof_used + 1] : nullptr;
+    if (timed) c->prof_used++;
     if (use_amg) {
-      spmv<9>(c, Avals(c), B.z2, B.Ap, B.part_pAp, nullptr, B.p, B.part_rz, B.part_zz, 0.0, parity);
+      spmv<9>(c, Avals(c), B.z2, B.Ap, B.part_pAp, nullptr, B.p, B.part_rz, B.part_zz, 0.0, parity, e0, e1);
       reduce(c, B.part_pAp, B.red->pAp);
       hipLaunchKernelGGL((kb_update<NV, true, DPC>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, B.red, parity, B.scal,
                          B.part_rz, B.part_zz, B.u, B.r, B.p, B.Ap, Dinv(c), c->amg[0].omega, B.z);
@@ -929,7 +941,7 @@ struct BatchOps {
       reduce(c, B.part_zz, B.red->zz, nullptr, nullptr, B.scal);
       vcycle(c, parity ^ 1);
     } else {
-      spmv<9>(c, Avals(c), B.z, B.Ap, B.part_pAp, nullptr, B.p, B.part_rz, B.part_zz, 0.0, parity);
+      spmv<9>(c, Avals(c), B.z, B.Ap, B.part_pAp, nullptr, B.p, B.part_rz, B.part_zz, 0.0, parity, e0, e1);
       reduce(c, B.part_pAp, B.red->pAp);
       hipLaunchKernelGGL((kb_update<NV, false, DPC>), dim3(B.Pb), dim3(TPB), 0, c->stream, c->n, B.red, parity, B.scal,
                          B.part_rz, B.part_zz, B.u, B.r, B.p, B.Ap, Dinv(c), 0.0, B.z);
@@ -991,6 +1003,21 @@ struct BatchOps {
 
   // PCG on all columns, started from B.u; iteration counts / residuals are left in B.h_scal
   static int pcg(hf_ctx* ctx, bool use_amg, double rtol, double atol, int max_it) {
+    if (!ctx->prof) return pcg_run(ctx, use_amg, rtol, atol, max_it);
+    ctx->prof_used = 0;
+    const int rc = pcg_run(ctx, use_amg, rtol, atol, max_it);
+    (void)hipStreamSynchronize(ctx->stream);
+    int most = 0;                                     // iteration heads that really ran: those of the slowest column
+    for (int j = 0; j < NV; ++j) most = std::max(most, ctx->batch.h_scal[j].iters);
+    for (int k = 0; k < ctx->prof_used && k < most; ++k) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->prof_ev[2 * k], ctx->prof_ev[2 * k + 1]) == hipSuccess) { ctx->prof_spmv_ms += ms; ctx->prof_spmv_n += 1; }
+    }
+    ctx->prof_used = 0;
+    return rc;
+  }
+
+  static int pcg_run(hf_ctx* ctx, bool use_amg, double rtol, double atol, int max_it) {
     hf_ctx::Batch& B = ctx->batch;
     // a new epoch instead of a reset of the mirrors: launches of the previous solve's blind burst may still be queued
     // (they publish nothing once their column has converged, and whatever reaches the mirrors late carries the old epoch)

@@ -369,6 +369,85 @@ def test_batched_sweeps_give_the_same_rows_and_files_as_point_by_point(tmp_path)
         wa = np.genfromtxt(os.path.join(a["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
         wb = np.genfromtxt(os.path.join(b["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
         assert np.abs(wa["oside"] - wb["oside"]).max() < 1e-9
+    # the reference's production sweep runs run_no_diamond (parameter_sweep.py:43): batched too, read-flux CSVs per point
+    cfgn = _cfg("geballe_no_diamond", 16.0, 6)
+    cfgn["heating"]["file"] = os.path.join(ROOT, cfgn["heating"]["file"])
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfgn, f)
+    made.clear()
+    ok_b, failed_b = ps.run_parameter_sweep(cfg_path, str(tmp_path / "nb"), *args[2:], base_mesh_folder=str(tmp_path / "nm"),
+                                            session_factory=factory, batch=8)
+    ok_1, failed_1 = ps.run_parameter_sweep(cfg_path, str(tmp_path / "n1"), *args[2:], base_mesh_folder=str(tmp_path / "nm"),
+                                            session_factory=_session_factory)
+    assert len(ok_b) == 6 and not failed_b and not failed_1 and [r.get("batch") for r in ok_b] == [4, 4, 4, 4, 2, 2]
+    assert made[0].backend.batch_flux_calls == 2
+    for a, b in zip(ok_b, ok_1):
+        for name in ("watcher_points.csv", "radial_gradient.csv", "radial_gradient_raw.csv"):
+            fa = np.genfromtxt(os.path.join(a["output_dir"], name), delimiter=",", skip_header=1)
+            fb = np.genfromtxt(os.path.join(b["output_dir"], name), delimiter=",", skip_header=1)
+            assert fa.shape == fb.shape and np.allclose(fa, fb, rtol=1e-9, atol=1e-6), name
+        with open(os.path.join(a["output_dir"], "radial_gradient_raw.csv")) as f1, open(os.path.join(b["output_dir"], "radial_gradient_raw.csv")) as f2:
+            assert f1.readline() == f2.readline()            # same header: time + z of the axis nodes
+
+
+def test_a_failed_batch_is_recorded_in_the_rows_and_the_points_are_rerun_one_by_one(tmp_path, capsys):
+    """SURVEY 5 (failure detection; reference parameter_sweep.py:154-192, :516-518): a batched time loop that does not
+    converge as a whole is re-run point by point, and every such row says so in `batch_error` (also in the CSV and on
+    stderr) - a batch that always fails must not look like a merely slow sweep.  A failure that is not a solver outcome
+    (here: a HIP error) is not retried: the points become failed rows."""
+    import csv
+    from heatflow_amd.driver import SimulationSession, prepare_mesh
+    from heatflow_amd.geometry import build_stack
+    from heatflow_amd.hip_backend import HipError, NotConverged
+
+    class FailingBatch(OracleBackend):
+        error = None
+        calls = 0
+
+        def batch_run(self, *a, **kw):
+            FailingBatch.calls += 1
+            raise FailingBatch.error
+
+    def factory(coords, tris, tags, tag_map, pattern=None):
+        return SimulationSession(coords, tris, tags, tag_map, backend=FailingBatch(), pattern=pattern)
+
+    # the no-diamond production grid (read-flux projection batched too): 2 x 2 points on one width
+    cfg = _cfg("geballe_no_diamond", 16.0, 6)
+    cfg["heating"]["file"] = os.path.join(ROOT, cfg["heating"]["file"])
+    cfg_path = str(tmp_path / "base.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    grid = ((8e-6, 2e-5), (3.0, 5.0), (1.84e-6, 1.84e-6), (2, 2, 1))
+    FailingBatch.error = NotConverged(-4, "batched PCG not converged in 7 iterations")
+    ok, failed = ps.run_parameter_sweep(cfg_path, str(tmp_path / "o1"), *grid, base_mesh_folder=str(tmp_path / "m"),
+                                        session_factory=factory, batch=8)
+    assert FailingBatch.calls == 1 and len(ok) == 4 and not failed
+    assert all("not converged in 7 iterations" in r["batch_error"] and r["status"] == "success" for r in ok)
+    assert all(os.path.isfile(os.path.join(r["output_dir"], "radial_gradient_raw.csv")) for r in ok)
+    with open(os.path.join(str(tmp_path / "o1"), "successful_runs.csv")) as f:
+        assert all("NotConverged" in r["batch_error"] for r in csv.DictReader(f))
+    assert "batched time loop of 4 points failed" in capsys.readouterr().err
+    # a device-side failure is not retried
+    FailingBatch.error, FailingBatch.calls = HipError(-3, "hipStreamSynchronize failed: illegal memory access"), 0
+    ok, failed = ps.run_parameter_sweep(cfg_path, str(tmp_path / "o2"), *grid, base_mesh_folder=str(tmp_path / "m"),
+                                        session_factory=factory, batch=8)
+    assert FailingBatch.calls == 1 and not ok and len(failed) == 4
+    assert all("illegal memory access" in r["error"] and r["batch_error"] for r in failed)
+    # the kappa-only sweep driver does the same
+    cfgw = _cfg("geballe_with_diamond", 16.0, 6)
+    cfgw["heating"]["file"] = os.path.join(ROOT, cfgw["heating"]["file"])
+    mesh = str(tmp_path / "mw")
+    prepare_mesh(cfgw, mesh, True, build_stack(cfgw))
+    FailingBatch.error, FailingBatch.calls = NotConverged(-4, "batched PCG breakdown"), 0
+    rows = ps.run_kappa_sweep(cfgw, mesh, [3.4, 3.8, 4.2, 4.6], str(tmp_path / "o3"), session_factory=factory, batch=4)
+    assert FailingBatch.calls == 1 and [r["status"] for r in rows] == ["success"] * 4 and all("breakdown" in r["batch_error"] for r in rows)
+    # configurations that do not share their watcher points cannot share a batch
+    from heatflow_amd.driver import run_simulation_batch_impl
+    sess = SimulationSession(*prepare_mesh(cfgw, mesh, False, build_stack(cfgw)), backend=OracleBackend())
+    wp = watcher_points(cfgw)
+    with pytest.raises(ValueError, match="share their watcher points"):
+        run_simulation_batch_impl("with_diamond", [cfgw, cfgw], [str(tmp_path / "a"), str(tmp_path / "b")],
+                                  [wp, {"pside": wp["pside"], "oside": (wp["oside"][0] + 1e-7, 0.0)}], sess)
 
 
 def test_root_level_modules_keep_the_reference_names():

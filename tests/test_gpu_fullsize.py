@@ -214,11 +214,43 @@ def test_c4_stock_read_flux_matches_oracle(hip, c2):
         prob.close()
 
 
+def test_c4_two_sided_heating_extension_at_stock_size(hip, c2):
+    """BASELINE config 4's "two-sided heating" on the stock no-diamond mesh.  EXTENSION WITHOUT A REFERENCE IMPLEMENTATION
+    (cfgs/konopkova.yaml is an unparseable stub, no two-sided code exists in the reference): a second Gaussian Dirichlet
+    line on the outer face of the o-side coupler driven by the CSV's `oside` column; checked against the oracle's
+    restatement of the same extension, 12 steps, every field."""
+    from conftest import HEATING_CSV, load_cfg
+    from heatflow_amd.driver import SimulationSession
+    from oracle import heat_oracle as ho
+
+    _, stack, mesh = c2
+    cfg = load_cfg("geballe_no_diamond_read_flux")
+    cfg["heating"]["file"] = HEATING_CSV
+    nsteps = 12
+    cfg["timing"]["num_steps"] = nsteps
+    cfg["timing"]["t_final"] = nsteps * 1.5e-7
+    ref = ho.run_reference_algorithm(cfg, mesh.coords, mesh.tris, mesh.tags, mesh.material_tags, HEATING_CSV, keep_fields=True,
+                                     second_line=stack.heated_z_oside)
+    one_sided = ho.run_reference_algorithm(cfg, mesh.coords, mesh.tris, mesh.tags, mesh.material_tags, HEATING_CSV, keep_fields=True)
+    fields = []
+    sess = SimulationSession(mesh.coords, mesh.tris, mesh.tags, mesh.material_tags)
+    try:
+        res = sess.run(cfg, stack, None, field_sink=lambda t, u: fields.append(u.copy()), read_flux=True, two_sided=True)
+    finally:
+        sess.close()
+    assert len(fields) == nsteps and len(sess.coords) > 1.0e5
+    worst = max(float(np.abs(f - r).max()) for f, r in zip(fields, ref["fields"]))
+    assert worst <= 1e-4, worst
+    assert np.abs(ref["fields"][-1] - one_sided["fields"][-1]).max() > 0.5        # the second line matters
+    assert res["flux"] is not None and len(res["flux"].rows) == nsteps
+    print(f"two-sided extension at stock size: worst |dT| = {worst:.2e} K over {nsteps} steps, {len(sess.coords)} DOF")
+
+
 def test_c5_sixty_four_point_kappa_sweep_on_one_gpu(hip, tmp_path):
-    """BASELINE C5 at its stated size on one GPU (a world of 1 takes all 64 points, 4 in flight): 64
-    kappa_sample values on the stock geballe_with_diamond mesh, 100 steps each (reference
-    parameter_sweep.py:423-446, sweep_test.py:47-115).  Every point must succeed; three of them (both ends
-    and the middle of the grid) are re-run by the oracle on the same mesh and compared at every step."""
+    """BASELINE C5 at its stated size on one GPU, as bench.py runs it (a world of 1 takes all 64 points: batches of 8
+    through the batched time loop, 2 loops in flight): 64 kappa_sample values on the stock geballe_with_diamond mesh,
+    100 steps each (reference parameter_sweep.py:423-446, sweep_test.py:47-115).  Every point must succeed; three of
+    them (both ends and the middle of the grid) are re-run by the oracle on the same mesh and compared at every step."""
     import copy
     import yaml
     from conftest import HEATING_CSV, load_cfg
@@ -234,9 +266,10 @@ def test_c5_sixty_four_point_kappa_sweep_on_one_gpu(hip, tmp_path):
     assert len(ks) == 64 and len({f"{k:.2f}" for k in ks}) == 64
     mesh_folder, out = str(tmp_path / "mesh"), str(tmp_path / "out")
     timing = {}
-    rows = ps.run_kappa_sweep(cfg, mesh_folder, ks, out, rebuild_mesh=True, concurrent=4, exp_csv=HEATING_CSV, timing=timing)
+    rows = ps.run_kappa_sweep(cfg, mesh_folder, ks, out, rebuild_mesh=True, concurrent=2, batch=8, exp_csv=HEATING_CSV, timing=timing)
     assert len(rows) == 64 and all(r["status"] == "success" for r in rows), [r["error"] for r in rows if r["error"]][:1]
-    assert [r["k"] for r in rows] == sorted(ks.tolist()) and timing["sessions"] == 4
+    assert [r["k"] for r in rows] == sorted(ks.tolist()) and timing["sessions"] == 2 and timing["batches"] == [8] * 8
+    assert all(r.get("batch") == 8 and not r.get("batch_error") for r in rows)
     assert all(np.isfinite(r["rmse"]) and 0.0 < r["rmse"] < 0.2 for r in rows)
     coords, tris, tags = load_mesh_arrays(os.path.join(mesh_folder, "mesh.msh"))
     mtags = yaml.safe_load(open(os.path.join(mesh_folder, "mesh_cfg.yaml")))["material_tags"]

@@ -487,6 +487,75 @@ def test_no_diamond_grid_sweep_every_point_succeeds_on_one_context(hip, tmp_path
         assert r["status"] == "success" and os.path.isfile(os.path.join(r["output_dir"], "radial_gradient.csv"))
 
 
+def test_no_diamond_grid_sweep_through_the_batched_loop_matches_the_oracle_at_every_point(hip, tmp_path):
+    """The reference's production sweep (parameter_sweep.py:43,157-166,195-235: fwhm x k x width over run_no_diamond with its
+    per-step read-flux projection, run_no_diamond.py:543-566,603-617) through the batched time loop: a 2 x 3 grid on one
+    width = one batch of 4 and one of 2 columns (affine operator family in k, boundary values per column in fwhm), the
+    projection as the columns of one Jacobi-PCG.  Every point: watcher curves and the last row of
+    radial_gradient_raw.csv (dT/dr on the axis nodes) against the oracle's run of that point; the files of the batched
+    sweep equal those of a point-by-point sweep to solver tolerance."""
+    import csv
+    import os
+    import yaml
+
+    from conftest import HEATING_CSV, load_cfg
+    from heatflow_amd import parameter_sweep as ps
+    from heatflow_amd.geometry import scale_mesh_sizes, watcher_points
+    from heatflow_amd.mesh import load_mesh_arrays
+    from heatflow_amd.solver import nearest_nodes
+    from oracle import heat_oracle as ho
+
+    cfg = scale_mesh_sizes(load_cfg("geballe_no_diamond_read_flux"), 3.0)
+    cfg["heating"]["file"] = HEATING_CSV
+    nsteps = 12
+    cfg["timing"]["num_steps"] = nsteps
+    cfg["timing"]["t_final"] = nsteps * 1.875e-7
+    cfg_path = str(tmp_path / "cfg.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    grid = ((1.0e-5, 1.4e-5), (3.4, 4.2), (1.9e-6, 1.9e-6), (2, 3, 1))
+    out_b, out_s = str(tmp_path / "out_batched"), str(tmp_path / "out_single")
+    ps.run_parameter_sweep(cfg_path, out_b, *grid, base_mesh_folder=str(tmp_path / "meshes"), batch=8)
+    ps.run_parameter_sweep(cfg_path, out_s, *grid, base_mesh_folder=str(tmp_path / "meshes"), batch=1)
+    with open(os.path.join(out_b, "successful_runs.csv")) as f:
+        rows = list(csv.DictReader(f))
+    failed = os.path.join(out_b, "failed_runs.csv")
+    assert len(rows) == 6, open(failed).read() if os.path.isfile(failed) else rows
+    assert sorted(int(r["batch"]) for r in rows) == [2, 2, 4, 4, 4, 4] and not any(r.get("batch_error") for r in rows)
+    mesh_folder = ps.get_mesh_folder_for_width(str(tmp_path / "meshes"), 1.9e-6)
+    coords, tris, tags = load_mesh_arrays(os.path.join(mesh_folder, "mesh.msh"))
+    mtags = yaml.safe_load(open(os.path.join(mesh_folder, "mesh_cfg.yaml")))["material_tags"]
+    proj = ho.GradientProjector(coords, tris)
+    axis = np.nonzero(np.abs(coords[:, 1]) <= 1e-12)[0]
+    axis = axis[np.argsort(coords[axis, 0], kind="stable")]
+    seen = set()
+    for r in rows:
+        c = ps.modify_config_for_parameters(cfg, float(r["fwhm"]), float(r["k"]), float(r["width"]))
+        nodes = nearest_nodes(coords, list(watcher_points(c).values()))
+        ref = ho.run_reference_algorithm(c, coords, tris, tags, mtags, HEATING_CSV, watcher_nodes=nodes, keep_fields=True)
+        got = np.genfromtxt(os.path.join(r["output_dir"], "watcher_points.csv"), delimiter=",", names=True)
+        assert len(got) == nsteps
+        assert np.abs(got["pside"] - ref["watchers"][:, 0]).max() <= FIELD_TOL_K
+        assert np.abs(got["oside"] - ref["watchers"][:, 1]).max() <= FIELD_TOL_K
+        with open(os.path.join(r["output_dir"], "radial_gradient_raw.csv")) as f:
+            raw = list(csv.reader(f))
+        assert len(raw) == nsteps + 1 and np.allclose(np.array(raw[0][1:], dtype=float), coords[axis, 0], rtol=0, atol=0)
+        g_ref = proj.project(ref["fields"][-1])[axis, 1]
+        g_got = np.array(raw[-1][1:], dtype=float)
+        scale = max(np.abs(g_ref).max(), 1.0)
+        assert scale > 1e5 and np.abs(g_got - g_ref).max() <= 1e-4 * scale + 1e-3
+        # the same point of the point-by-point sweep: same files to solver tolerance
+        single = os.path.join(out_s, os.path.basename(r["output_dir"]))
+        got_s = np.genfromtxt(os.path.join(single, "watcher_points.csv"), delimiter=",", names=True)
+        assert np.abs(got["oside"] - got_s["oside"]).max() <= 1e-5 and np.abs(got["pside"] - got_s["pside"]).max() <= 1e-5
+        for name in ("radial_gradient.csv", "radial_gradient_raw.csv"):
+            a = np.genfromtxt(os.path.join(r["output_dir"], name), delimiter=",", skip_header=1)
+            b = np.genfromtxt(os.path.join(single, name), delimiter=",", skip_header=1)
+            assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4 * scale + 1e-3
+        seen.add((round(float(r["fwhm"]), 9), round(float(r["k"]), 6)))
+    assert len(seen) == 6
+
+
 def _unit_square_mesh(nz, nr):
     z = np.linspace(0.0, 1.0e-6, nz + 1)
     r = np.linspace(0.0, 2.0e-6, nr + 1)
