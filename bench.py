@@ -431,14 +431,23 @@ def run_sweep64(ranks, n_points, steps_per_point, warmup_steps, concurrent, batc
     wall = ranks.max_over_ranks(clock["all"])
     whole = ranks.max_over_ranks(t_all)          # mesh + broadcasts + connectivity tables + multigrid set-up + warm-up + point loop, slowest rank
     setup_max = ranks.max_over_ranks(t_all - clock["all"])
+    phase_keys = ("mesh_s", "broadcast_s", "pattern_build_s", "pattern_broadcast_s", "hierarchy_build_s", "hierarchy_broadcast_s",
+                  "session_s", "warmup_s", "mesh_received_to_ready_s", "points_s", "close_s", "gather_write_s")
+    mine = {k: timing.get(k) for k in phase_keys}
+    by_rank = [mine]
+    if ranks.dist is not None:
+        by_rank = [None] * ranks.world
+        ranks.dist.all_gather_object(by_rank, mine)
     if ranks.rank != 0:
         return None
     bad = [r for r in rows if r["status"] != "success"]
     if bad:
         raise SystemExit(f"bench.py: {len(bad)} sweep point(s) failed, first: {bad[0]['error']}")
     import numpy as np
-    with open(os.path.join(ROOT, "cfgs", "geballe_with_diamond.yaml")) as f:
-        n_dof = _stock_dof(yaml.safe_load(f))
+    n_dof = timing.get("n_dof")                  # rank 0 built the mesh
+    if not n_dof:
+        with open(os.path.join(ROOT, "cfgs", "geballe_with_diamond.yaml")) as f:
+            n_dof = _stock_dof(yaml.safe_load(f))
     return {
         "workload": (f"{n_points}-point kappa_sample sweep [{ks[0]}..{ks[-1]}] on cfgs/geballe_with_diamond.yaml, stock mesh "
                      f"(BASELINE C5), point i -> rank i mod {ranks.world}, batches of up to {batch} points per time loop, "
@@ -452,7 +461,8 @@ def run_sweep64(ranks, n_points, steps_per_point, warmup_steps, concurrent, batc
             "one_run_per_point": 12 * 7 + 44, "batched": (4 + 16) * 7 / max(batch, 1) + 44 if batch > 1 else 12 * 7 + 44},
         "wall_s": wall, "value": n_points * n_dof * steps_per_point / wall, "unit": "DOF-updates/s",
         "points_per_s": n_points / wall, "pcg_iters_per_step_mean": float(np.mean([r["pcg_iters_mean"] for r in rows])),
-        "rank0_phases_s": {k: timing.get(k) for k in ("mesh_s", "broadcast_s", "pattern_build_s", "pattern_broadcast_s", "session_s", "warmup_s", "points_s")},
+        "rank0_phases_s": by_rank[0], "other_ranks_phases_s": by_rank[1:],
+        "n_dof_check": timing.get("n_dof"),
         "whole_call_s": whole, "setup_s_max_over_ranks": setup_max,
         "value_whole_call": n_points * n_dof * steps_per_point / whole,
         "value_whole_call_note": ("the same DOF-updates over the whole call of the slowest rank: mesh, broadcasts, connectivity tables, "

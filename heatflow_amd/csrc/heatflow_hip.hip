@@ -10,7 +10,7 @@
 // Reference semantics being reproduced: run_with_diamond.py:321-337 (forms), :381-394 (assemble
 // once, symmetric Dirichlet elimination, solve), :469-481 (loop body).
 
-#include "hf_batch.hpp"
+#include "hf_amg_io.hpp"
 
 // ==========================================================================================
 // C ABI
@@ -36,7 +36,6 @@ struct BlobHeader {
   int32_t n, ne, rba, ts, max_blk_nnz, tab_len, rg_ok, rg_max_dict, spmv_max_dict, reserved;
   int64_t count[12];            // elements per section, in the order written below
 };
-inline size_t pad16(size_t b) { return (b + 15) & ~static_cast<size_t>(15); }
 
 // Upload the tables and size every buffer of the context for the mesh.
 int install_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int32_t* tri, const int32_t* tag, MeshTables& T) {
@@ -410,6 +409,10 @@ int hf_create(int device_id, hf_ctx** out) {
   if (rc == HF_OK) rc = dev_alloc(ctx, &ctx->d_part_zz, MAXP);
   if (rc == HF_OK) rc = dev_alloc(ctx, &ctx->d_part_bn, MAXP);
   if (rc == HF_OK && reset_scal(ctx) != HF_OK) rc = HF_ERR_HIP;
+  if (rc == HF_OK) {     // an empty launch: the library's device code is loaded now (tens of ms once per process), not inside the first solve
+    hipLaunchKernelGGL(k_zero_entries, dim3(1), dim3(64), 0, ctx->stream, 0, static_cast<const int32_t*>(nullptr), static_cast<double*>(nullptr));
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, HF_ERR_HIP, "first kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+  }
   *out = ctx;
   return rc;
 }
@@ -584,8 +587,18 @@ int hf_assemble(hf_ctx* ctx, double dt, int32_t mode) {
   float ms = 0.f;
   HF_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->last_ms = ms;
-  if (ctx->precond == 1 && !(ctx->amg_ready && ctx->amg_reuse)) HF_TRY(build_amg(ctx));
-  else if (ctx->precond == 1) ctx->amg_fine_stale = true;      // hierarchy kept (reuse): its fused fine-level operators hold the old A
+  if (ctx->precond == 1) {
+    OperatorPrint now;
+    HF_TRY(operator_print(ctx, now));
+    if (!(ctx->amg_ready && ctx->amg_reuse)) {
+      HF_TRY(build_amg(ctx));
+      ctx->amg_print = std::move(now);
+    } else {
+      // hierarchy kept (reuse) or installed from another context (hf_amg_install): its fused fine-level operators hold the
+      // operator it was built from - usable only if that is this one
+      ctx->amg_fine_stale = !same_print(now, ctx->amg_print);
+    }
+  }
   if (ctx->precond == 1 && ctx->amg_ready) {  // level 0 aliases the fine operator: refresh its pointers
     ctx->amg[0].A.val = ctx->d_A;
     ctx->amg[0].dinv = ctx->d_dinv;
@@ -637,6 +650,47 @@ int hf_get_amg_info(hf_ctx* ctx, int32_t* n_levels, int32_t* level_rows, int32_t
     for (int l = 0; l < nl && l < max_levels; ++l) level_rows[l] = ctx->amg[l].n;
   if (op_complexity) *op_complexity = ctx->amg_ready ? ctx->amg_opc : 0.0;
   if (setup_seconds) *setup_seconds = ctx->amg_ready ? ctx->amg_setup_s : 0.0;
+  return HF_OK;
+}
+
+int hf_amg_export_size(hf_ctx* ctx, int64_t* bytes) {
+  if (!ctx || !bytes) return HF_ERR_ARG;
+  if (!ctx->amg_ready || !ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_amg_export_size: no multigrid hierarchy (hf_set_precond(1, ...) and hf_assemble first)");
+  BlobOut o;
+  o.ctx = ctx;
+  HF_TRY(walk_hierarchy(ctx, o, ctx->amg_print));
+  *bytes = static_cast<int64_t>(o.at);
+  return HF_OK;
+}
+
+int hf_amg_export(hf_ctx* ctx, void* blob, int64_t bytes) {
+  if (!ctx || !blob) return HF_ERR_ARG;
+  if (!ctx->amg_ready || !ctx->assembled) return fail(ctx, HF_ERR_STATE, "hf_amg_export: no multigrid hierarchy (hf_set_precond(1, ...) and hf_assemble first)");
+  HF_HIP(hipSetDevice(ctx->dev));
+  BlobOut sz;
+  sz.ctx = ctx;
+  HF_TRY(walk_hierarchy(ctx, sz, ctx->amg_print));
+  if (bytes != static_cast<int64_t>(sz.at)) return fail(ctx, HF_ERR_ARG, "hf_amg_export: buffer of %lld bytes, need %lld", (long long)bytes, (long long)sz.at);
+  std::vector<unsigned char> host(sz.at, 0);
+  BlobOut o;
+  o.ctx = ctx;
+  o.dst = host.data();
+  HF_TRY(walk_hierarchy(ctx, o, ctx->amg_print));
+  HF_HIP(hipStreamSynchronize(ctx->stream));
+  HF_HIP(hipMemcpy(blob, host.data(), host.size(), hipMemcpyDefault));     // host or device destination
+  return HF_OK;
+}
+
+int hf_amg_install(hf_ctx* ctx, const void* blob, int64_t bytes) {
+  if (!ctx || !blob || bytes <= 0) return HF_ERR_ARG;
+  if (!ctx->have_mesh) return fail(ctx, HF_ERR_STATE, "hf_amg_install before hf_set_mesh");
+  if (ctx->precond != 1 || !ctx->amg_reuse) return fail(ctx, HF_ERR_STATE, "hf_amg_install needs hf_set_precond(1, reuse = 1): an installed hierarchy is a kept one");
+  HF_HIP(hipSetDevice(ctx->dev));
+  free_batch(ctx);
+  std::vector<unsigned char> host(static_cast<size_t>(bytes));             // the blob may live on the host or on a device
+  HF_HIP(hipMemcpy(host.data(), blob, static_cast<size_t>(bytes), hipMemcpyDefault));
+  HF_TRY(install_hierarchy(ctx, host.data(), host.size()));
+  ctx->assembled = false;            // the next hf_assemble compares its operator with the hierarchy's fingerprint
   return HF_OK;
 }
 

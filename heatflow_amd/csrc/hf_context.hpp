@@ -186,6 +186,7 @@ struct hf_ctx {
     int32_t *dptr = nullptr, *dict = nullptr;  // stream kernel with compressed columns: per-chunk column lists ...
     uint16_t* cid = nullptr;                   // ... and a 16-bit position per nonzero
     int max_dict = 0;
+    int64_t ndict = 0;                         // entries of `dict` (all chunks)
   };
   // Levels 1..nl-2 run the cycle through the fused legs Rt / GP (amg_host.hpp): `cat` = [b_l ; result of level l+1]
   // is GP's operand, `b` aliases its head; a level's result goes to `res` (the tail of the finer level's cat,
@@ -204,6 +205,9 @@ struct hf_ctx {
   int amg_fuse0 = 0;                 // finest level of the V-cycle: 0 explicit sweeps, 1 fused legs Rt_0 / GP_0, 2 fused down leg only (chosen by size in build_amg; HEATFLOW_AMG_FUSE0 overrides)
   bool amg_f32 = true;               // operators of the preconditioner below the fine level stored in float (HEATFLOW_AMG_F32=0: double)
   double amg_opc = 0.0, amg_setup_s = 0.0;
+  // what the fine operator the hierarchy was built from depends on besides the mesh (hf_amg_io.hpp): time step, coefficient
+  // tables, Dirichlet set - compared with the context's own operator whenever a kept or installed hierarchy meets a new hf_assemble
+  struct OperatorPrint { double dt = 0.0; std::vector<double> kappa, rhoc; int32_t nbc = 0; uint64_t bc_hash = 0; } amg_print;
   long long amg_fallbacks = 0;   // steps finished by Jacobi-PCG after a multigrid-PCG breakdown
   double *d_z = nullptr, *d_z2 = nullptr;
   // read-flux projection (hf_flux_setup): unit-rho_c r-weighted mass matrix and the projected gradient
@@ -260,6 +264,7 @@ struct hf_ctx {
 namespace {
 
 int fail(hf_ctx* c, int code, const char* fmt, ...);
+inline size_t pad16(size_t b) { return (b + 15) & ~static_cast<size_t>(15); }
 
 // a polite spin: the polling threads of concurrent sessions share host cores with the threads that launch kernels
 inline void cpu_relax() {

@@ -63,12 +63,46 @@ int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d, bool f32 = false, bool
     ColDict cd;
     if (build_coldict(h.ptr, h.idx, h.nrow, d.rpc, cd, h.ncol) && static_cast<size_t>(d.chunk_nnz + cd.max_dict) * 8 <= 64 * 1024) {
       d.max_dict = cd.max_dict;
+      d.ndict = static_cast<int64_t>(cd.dict.size());
       HF_TRY(dev_alloc(ctx, &d.dptr, cd.ptr.size()));
       HF_TRY(dev_alloc(ctx, &d.dict, cd.dict.size()));
       HF_TRY(dev_alloc(ctx, &d.cid, cd.id.size()));
       HF_HIP(copy_sync(ctx, d.dptr, cd.ptr.data(), sizeof(int32_t) * cd.ptr.size(), hipMemcpyHostToDevice));
       HF_HIP(copy_sync(ctx, d.dict, cd.dict.data(), sizeof(int32_t) * cd.dict.size(), hipMemcpyHostToDevice));
       HF_HIP(copy_sync(ctx, d.cid, cd.id.data(), sizeof(uint16_t) * cd.id.size(), hipMemcpyHostToDevice));
+    }
+  }
+  return HF_OK;
+}
+
+// Level vectors and aliases once every level's operators are on the device (build_amg, hf_amg_install): level 0 is the
+// context's own operator; an intermediate level's right-hand side b is the head of `cat` = [b_l ; result of level l + 1],
+// the operand of its fused up leg; a level's result goes to `res` (the tail of the finer level's cat, or - level 1 - its
+// own x, or behind d_r when the finest level's up leg is fused); the coarsest level owns a zero-padded b.
+int wire_levels(hf_ctx* ctx) {
+  const size_t nl = ctx->amg.size();
+  for (size_t l = 0; l < nl; ++l) {
+    DevLevel& L = ctx->amg[l];
+    if (l == 0) {
+      L.A.nrow = L.A.ncol = ctx->n; L.A.nnz = ctx->nnz; L.A.ptr = ctx->d_rowptr; L.A.idx = ctx->d_colidx; L.A.val = ctx->d_A;
+      L.dinv = ctx->d_dinv;
+      continue;
+    }
+    if (l + 1 < nl) {
+      const size_t len = static_cast<size_t>(L.n) + ctx->amg[l + 1].n + 2;
+      HF_TRY(dev_alloc(ctx, &L.cat, len));
+      HF_HIP(hipMemsetAsync(L.cat, 0, sizeof(double) * len, ctx->stream));
+      L.b = L.cat;
+    } else {
+      HF_TRY(dev_alloc(ctx, &L.b, L.n + 4));
+      L.own_b = true;
+      HF_HIP(hipMemsetAsync(L.b, 0, sizeof(double) * (L.n + 4), ctx->stream));
+    }
+    if (l == 1) {
+      HF_TRY(dev_alloc(ctx, &L.x, L.n + 2));
+      L.res = ctx->amg[0].GP.nrow > 0 ? ctx->d_r + ctx->n : L.x;
+    } else {
+      L.res = ctx->amg[l - 1].cat + ctx->amg[l - 1].n;
     }
   }
   return HF_OK;
@@ -119,8 +153,6 @@ int build_amg(hf_ctx* ctx) {
     L.n = static_cast<int>(hl.dinv.size());
     L.omega = hl.omega;
     if (l == 0) {
-      L.A.nrow = L.A.ncol = ctx->n; L.A.nnz = ctx->nnz; L.A.ptr = ctx->d_rowptr; L.A.idx = ctx->d_colidx; L.A.val = ctx->d_A;
-      L.dinv = ctx->d_dinv;
       if (nl > 1 && hl.Rt.nrow > 0) {            // fused finest level: GP's operand is [r; x_1] = d_r with the level-1 result behind it
         HF_TRY(upload_csr(ctx, hl.Rt, L.Rt, f32));
         if (hl.GP.nrow > 0) HF_TRY(upload_csr(ctx, hl.GP, L.GP, f32));
@@ -133,23 +165,9 @@ int build_amg(hf_ctx* ctx) {
       HF_TRY(upload_csr(ctx, hl.A, L.A));
       HF_TRY(dev_alloc(ctx, &L.dinv, L.n));
       HF_HIP(copy_sync(ctx, L.dinv, hl.dinv.data(), sizeof(double) * L.n, hipMemcpyHostToDevice));
-      if (l + 1 < nl) {                       // intermediate level: b is the head of GP's operand
-        const size_t len = static_cast<size_t>(L.n) + hl.P.ncol + 2;
-        HF_TRY(dev_alloc(ctx, &L.cat, len));
-        HF_HIP(hipMemsetAsync(L.cat, 0, sizeof(double) * len, ctx->stream));
-        L.b = L.cat;
+      if (l + 1 < nl) {                       // intermediate level: the cycle runs through its fused legs
         HF_TRY(upload_csr(ctx, hl.Rt, L.Rt, f32));
         HF_TRY(upload_csr(ctx, hl.GP, L.GP, f32));
-      } else {                                // coarsest: the dense solve reads b in pairs -> zero pad
-        HF_TRY(dev_alloc(ctx, &L.b, L.n + 4));
-        L.own_b = true;
-        HF_HIP(hipMemsetAsync(L.b, 0, sizeof(double) * (L.n + 4), ctx->stream));
-      }
-      if (l == 1) {
-        HF_TRY(dev_alloc(ctx, &L.x, L.n + 2));
-        L.res = ctx->amg[0].GP.nrow > 0 ? ctx->d_r + ctx->n : L.x;
-      } else {
-        L.res = ctx->amg[l - 1].cat + ctx->amg[l - 1].n;
       }
     }
     if (l + 1 < nl) {
@@ -170,6 +188,7 @@ int build_amg(hf_ctx* ctx) {
       show("Rt", l, ctx->amg[l].Rt); show("GP", l, ctx->amg[l].GP);
     }
   }
+  HF_TRY(wire_levels(ctx));
   lap("+ operators uploaded");
   // coarsest level: dense inverse by Gauss-Jordan on the device
   ctx->coarse_n = 0;

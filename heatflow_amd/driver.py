@@ -97,8 +97,23 @@ def _parse_watchers(watcher_points):
     raise ValueError("watcher_points must be a dict or list of dicts")
 
 
-def prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack):
-    """Build-and-cache or load the mesh.  Returns (coords, tris, tags, material_tags)."""
+_pending_mesh_writes = []
+
+
+def flush_mesh_writes():
+    """Wait for the mesh-cache files a ``prepare_mesh(..., defer_write=True)`` left to a background thread."""
+    while _pending_mesh_writes:
+        th, err = _pending_mesh_writes.pop()
+        th.join()
+        if err:
+            raise err[0]
+
+
+def prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack, defer_write=False):
+    """Build-and-cache or load the mesh.  Returns (coords, tris, tags, material_tags).  ``defer_write``: the cache files
+    (``mesh.msh``, its sidecar, ``mesh_cfg.yaml``: 0.1 s of ASCII at 2e5 nodes) are written by a background thread while
+    the caller goes on with the arrays - a sweep broadcasts them and never reads the files back; :func:`flush_mesh_writes`
+    waits for them."""
     mesh_cfg_path = os.path.join(mesh_folder, "mesh_cfg.yaml")
     mesh_file_path = os.path.join(mesh_folder, "mesh.msh")
     if rebuild_mesh:
@@ -108,9 +123,26 @@ def prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack):
         os.makedirs(mesh_folder, exist_ok=True)
         mesh_cfg = copy.deepcopy(cfg)
         mesh_cfg["material_tags"] = tag_map
-        with open(mesh_cfg_path, "w") as f:
-            _dump_yaml(mesh_cfg, f)
-        mesh.write(mesh_file_path)
+
+        def write_files():
+            with open(mesh_cfg_path, "w") as f:
+                _dump_yaml(mesh_cfg, f)
+            mesh.write(mesh_file_path)
+
+        if defer_write:
+            err = []
+
+            def guarded():
+                try:
+                    write_files()
+                except BaseException as e:      # noqa: BLE001 - re-raised by flush_mesh_writes
+                    err.append(e)
+
+            th = threading.Thread(target=guarded, name="heatflow-mesh-write", daemon=False)
+            th.start()
+            _pending_mesh_writes.append((th, err))
+        else:
+            write_files()
         return mesh.coords, mesh.tris, mesh.tags, tag_map
     missing = [nm for nm, p in (("mesh.msh", mesh_file_path), ("mesh_cfg.yaml", mesh_cfg_path)) if not os.path.isfile(p)]
     if missing:
@@ -141,7 +173,7 @@ class SimulationSession:
     """
 
     def __init__(self, coords, tris, tags, material_tags, *, device_id=0, backend=None, rtol=DEFAULT_RTOL,
-                 max_it=DEFAULT_MAX_IT, assembly_mode=3, precond=1, pattern=None):
+                 max_it=DEFAULT_MAX_IT, assembly_mode=3, precond=1, pattern=None, hierarchy=None):
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.tris = np.ascontiguousarray(tris, dtype=np.int32)
         self.tags = np.ascontiguousarray(tags, dtype=np.int32)
@@ -150,6 +182,9 @@ class SimulationSession:
         self.rtol, self.max_it, self.assembly_mode = rtol, max_it, assembly_mode
         self.precond = precond           # 1 = multigrid-preconditioned CG (default), 0 = Jacobi-PCG
         self.pattern = pattern           # connectivity tables built once for this mesh (build_pattern_blob), or None
+        # multigrid hierarchy another session built on this mesh: {"blob": HeatflowHIP.amg_export() output, "k": {cell tag:
+        # conductivity it was built for}}; installed by the first problem this session creates instead of a host set-up
+        self.hierarchy = hierarchy
         self.problem = None
         self._key = None
         self._tree = None
@@ -160,6 +195,21 @@ class SimulationSession:
         if self.problem is not None:
             self.problem.close()
             self.problem = None
+
+    def export_hierarchy(self, into=None):
+        """The multigrid hierarchy of the resident problem for other sessions on this mesh (``hierarchy=`` of their
+        constructor): {"blob": uint8 array (or None when written ``into`` = (address, nbytes)), "k": {cell tag: conductivity}}."""
+        if self.problem is None or self.precond != 1:
+            raise RuntimeError("export_hierarchy: no resident problem with the multigrid preconditioner")
+        return {"blob": self.problem.backend.amg_export(into=into), "k": dict(self._k_hier)}
+
+    def prepare(self, cfg, stack):
+        """Create the resident problem for ``cfg`` (mesh tables, matrices, multigrid hierarchy) without running a step."""
+        num_steps = int(cfg["timing"]["num_steps"])
+        dt = float(cfg["timing"]["t_final"]) / num_steps
+        bcs = self._boundary_conditions(cfg, stack)
+        tag_to_k, tag_to_rc = self._tables(stack)
+        self._ensure_problem(self._problem_key(dt, tag_to_rc, bcs), tag_to_k, tag_to_rc, dt, bcs, float(cfg["heating"]["ic_temp"]))
 
     def _tables(self, stack):
         tag_to_k = {self.material_tags[m.name]: m.properties["k"] for m in stack.materials}
@@ -205,13 +255,23 @@ class SimulationSession:
         if self.problem is None or key != self._key:
             self.close()
             print("Assigning material properties...")
+            shared = self.hierarchy if (self.hierarchy is not None and self.precond == 1) else None
             self.problem = HeatProblem(self.coords, self.tris, self.tags, tag_to_k, tag_to_rc, dt, bcs, ic_temp,
                                        backend=self.backend, device_id=self.device_id, rtol=self.rtol,
                                        max_it=self.max_it, assembly_mode=self.assembly_mode, precond=self.precond,
-                                       amg_reuse=True, pattern=self.pattern)
+                                       amg_reuse=True, pattern=self.pattern, amg=shared["blob"] if shared else None)
             self._key = key
             self._k = dict(tag_to_k)
-            self._k_hier = dict(tag_to_k)            # conductivities the multigrid levels were built for
+            # conductivities the multigrid levels were built for: this problem's, or those of the session that shared them
+            self._k_hier = dict(shared["k"]) if shared else dict(tag_to_k)
+            self.hierarchy = None                    # a later problem of this session (other dt / Dirichlet set) builds its own
+            if shared and set(self._k_hier) == set(tag_to_k):
+                drift = max(max(tag_to_k[t] / self._k_hier[t], self._k_hier[t] / tag_to_k[t]) for t in tag_to_k)
+                if drift > 2.0:                      # too far from this point's operator to be a good frozen hierarchy: rebuild
+                    self.problem.backend.set_precond(1, False)
+                    self.problem.set_materials(tag_to_k, tag_to_rc)
+                    self.problem.backend.set_precond(1, True)
+                    self._k_hier = dict(tag_to_k)
             print("Material properties assigned.")
             return
         self.problem.bcs = bcs
@@ -236,10 +296,8 @@ class SimulationSession:
         names, coords_w = _parse_watchers(watcher_points)
         if not names:
             return names, None
-        if self._tree is None:                      # nearest-node lookup structure: once per resident mesh
-            from scipy.spatial import cKDTree
-            self._tree = cKDTree(self.coords)
-        return names, np.array([self._tree.query(p)[1] for p in coords_w], dtype=np.int32)
+        from .solver import nearest_nodes
+        return names, nearest_nodes(self.coords, coords_w)
 
     def run_batch(self, cfgs, stacks, watcher_points=None, read_flux=False):
         """``len(cfgs)`` in (2, 4, 8, 16) simulations of this mesh advanced together (hf_batch_*): the points of a

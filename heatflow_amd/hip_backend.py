@@ -22,7 +22,7 @@ BATCH_SHARED, BATCH_PER_COLUMN, BATCH_AFFINE = 0, 1, 2
 
 EXPORTS = [
     "hf_version", "hf_create", "hf_destroy", "hf_last_error", "hf_set_mesh", "hf_set_mesh_prebuilt", "hf_pattern_export_size",
-    "hf_pattern_export", "hf_set_materials",
+    "hf_pattern_export", "hf_amg_export_size", "hf_amg_export", "hf_amg_install", "hf_set_materials",
     "hf_update_kappa", "hf_set_dirichlet", "hf_assemble", "hf_set_precond", "hf_set_start_vector", "hf_get_response_solves", "hf_get_amg_info", "hf_get_amg_fallbacks", "hf_set_state", "hf_get_state", "hf_sample", "hf_step", "hf_run",
     "hf_batch_begin", "hf_batch_load_column", "hf_batch_set_affine", "hf_batch_set_state", "hf_batch_get_state", "hf_batch_run", "hf_batch_run_flux", "hf_batch_end",
     "hf_flux_setup", "hf_flux_project", "hf_flux_solve", "hf_flux_sample", "hf_get_sizes", "hf_get_csr", "hf_spmv", "hf_time_kernel", "hf_set_profile", "hf_get_profile", "hf_last_gpu_ms",
@@ -88,6 +88,9 @@ def load_library():
         "hf_set_mesh_prebuilt": [vp, i32, i32, pd, pi, pi, vp, i64],
         "hf_pattern_export_size": [vp, C.POINTER(i64)],
         "hf_pattern_export": [vp, vp, i64],
+        "hf_amg_export_size": [vp, C.POINTER(i64)],
+        "hf_amg_export": [vp, vp, i64],
+        "hf_amg_install": [vp, vp, i64],
         "hf_set_materials": [vp, i32, pi, pd, pd],
         "hf_update_kappa": [vp, i32, pi, pd],
         "hf_set_dirichlet": [vp, i32, pi],
@@ -128,6 +131,18 @@ def load_library():
         fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+def blob_address(blob):
+    """(address, nbytes) of a blob handed to set_mesh(pattern=) / amg_install: a uint8 numpy array, an ``(address, nbytes)``
+    tuple, or any object with ``address`` / ``nbytes`` attributes (a device-resident buffer kept alive by its owner, e.g. the
+    tensor a sweep received over RCCL: :class:`heatflow_amd.parameter_sweep.DeviceBlob`)."""
+    if isinstance(blob, tuple):
+        return int(blob[0]), int(blob[1]), blob
+    if hasattr(blob, "address") and hasattr(blob, "nbytes") and not isinstance(blob, np.ndarray):
+        return int(blob.address), int(blob.nbytes), blob
+    arr = np.ascontiguousarray(blob, dtype=np.uint8)
+    return arr.ctypes.data, arr.nbytes, arr
 
 
 def _pd(a):
@@ -201,11 +216,7 @@ class HeatflowHIP:
         if pattern is None:
             self._check(self._lib.hf_set_mesh(self._ctx, zr.shape[0], tri.shape[0], _pd(zr), _pi(tri), _pi(tag)))
         else:
-            if isinstance(pattern, tuple):
-                addr, nbytes = int(pattern[0]), int(pattern[1])
-            else:
-                pattern = np.ascontiguousarray(pattern, dtype=np.uint8)
-                addr, nbytes = pattern.ctypes.data, pattern.nbytes
+            addr, nbytes, _keep = blob_address(pattern)
             self._check(self._lib.hf_set_mesh_prebuilt(self._ctx, zr.shape[0], tri.shape[0], _pd(zr), _pi(tri), _pi(tag),
                                                        C.c_void_p(addr), nbytes))
         self._refresh_sizes()
@@ -228,6 +239,27 @@ class HeatflowHIP:
         blob = np.empty(nb, dtype=np.uint8)
         self._check(self._lib.hf_pattern_export(self._ctx, C.c_void_p(blob.ctypes.data), nb))
         return blob
+
+    def amg_export(self, into=None):
+        """The multigrid hierarchy of this context (assembled with PC_AMG) as one uint8 array, for ``amg_install`` of other
+        contexts on the same mesh.  ``into = (address, nbytes)`` writes to that host or device buffer and returns None."""
+        nb = C.c_int64()
+        self._check(self._lib.hf_amg_export_size(self._ctx, C.byref(nb)))
+        if into is not None:
+            if int(into[1]) != nb.value:
+                raise ValueError(f"amg_export: buffer of {into[1]} bytes, need {nb.value}")
+            self._check(self._lib.hf_amg_export(self._ctx, C.c_void_p(int(into[0])), nb.value))
+            return None
+        blob = np.empty(nb.value, dtype=np.uint8)
+        self._check(self._lib.hf_amg_export(self._ctx, C.c_void_p(blob.ctypes.data), nb.value))
+        return blob
+
+    def amg_install(self, blob):
+        """Install a hierarchy another context exported (after set_dirichlet and set_precond(PC_AMG, reuse=True), before
+        assemble): nothing is built on the host; assemble() then decides from the blob's fingerprint whether this context's
+        operator is the one the hierarchy was built from."""
+        addr, nbytes, _keep = blob_address(blob)
+        self._check(self._lib.hf_amg_install(self._ctx, C.c_void_p(addr), nbytes))
 
     def _refresh_sizes(self):
         n, ne, nbc, nnz = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()

@@ -32,7 +32,8 @@ import yaml
 
 import sys
 
-from .driver import SimulationSession, build_pattern_blob, prepare_mesh, run_simulation_batch_impl, run_simulation_impl
+from .driver import (SimulationSession, build_pattern_blob, flush_mesh_writes, prepare_mesh, run_simulation_batch_impl,
+                     run_simulation_impl)
 from .geometry import build_stack, watcher_points as _watcher_points
 from .hip_backend import HipError, NotConverged
 
@@ -84,12 +85,11 @@ def run_name_for(fwhm, k, width):
 
 # -- process group helpers (work without torch.distributed as a world of 1) ------------------
 def _dist():
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist
-    except ImportError:
-        pass
+    """torch.distributed if a process group is up.  A process that never imported it has none: a world of one must not
+    pay for ``import torch`` (0.9 s, most of a small sweep's set-up)."""
+    dist = sys.modules.get("torch.distributed")
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        return dist
     return None
 
 
@@ -116,7 +116,10 @@ def broadcast_mesh(arrays, tag_map=None, src=0):
     {material name: cell tag} from ``src`` to all ranks; returns (arrays, tag_map).  The tag map
     belongs to the mesh (``mesh_cfg.yaml``: gmsh surface ids for a reference-written mesh, list
     positions for ours), so every rank must use rank ``src``'s copy and never guess it.
-    With the nccl backend the arrays travel GPU-to-GPU (RCCL over xGMI), with gloo on the host."""
+    With the nccl backend the arrays travel GPU-to-GPU (RCCL over xGMI), with gloo on the host.  They end on the host on
+    every rank because the host logic needs them there: Dirichlet DOF location, nearest-node search of the watchers, the
+    flux bands, and the C ABI's hf_set_mesh(_prebuilt), which takes the mesh arrays as host pointers.  The two big blobs of
+    a sweep - connectivity tables and multigrid hierarchy - stay in device memory (:func:`broadcast_bytes`)."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return arrays, tag_map
@@ -142,8 +145,22 @@ def broadcast_mesh(arrays, tag_map=None, src=0):
     return tuple(out), box[0]
 
 
+class DeviceBlob:
+    """A blob in device memory (the tensor RCCL delivered it into), handed to the solver library by address:
+    ``hf_set_mesh_prebuilt`` / ``hf_amg_install`` read it from there, it never passes through host memory on this side."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor                      # keeps the memory alive
+        self.address = int(tensor.data_ptr())
+        self.nbytes = int(tensor.numel() * tensor.element_size())
+
+    def __len__(self):
+        return self.nbytes
+
+
 def broadcast_bytes(blob, src=0):
-    """Broadcast a uint8 array (the pattern blob) from ``src``; GPU-to-GPU with nccl, on the host with gloo."""
+    """Broadcast a uint8 array (pattern blob, hierarchy blob) from ``src``.  With nccl it travels GPU-to-GPU (RCCL over
+    xGMI) and STAYS on the device: every rank gets a :class:`DeviceBlob`; with gloo a numpy array on the host."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return blob
@@ -157,19 +174,30 @@ def broadcast_bytes(blob, src=0):
     t = torch.from_numpy(np.ascontiguousarray(blob, dtype=np.uint8)).to(dev) if rank == src else \
         torch.empty(int(size[0]), dtype=torch.uint8, device=dev)
     d.broadcast(t, src)
-    return t.cpu().numpy()
+    if on_gpu:
+        torch.cuda.synchronize()                 # the library reads the buffer on its own stream
+        return DeviceBlob(t)
+    return t.numpy()
 
 
-def shared_pattern(arrays, device_id, session_factory, pattern_builder, timing=None):
+def shared_pattern(arrays, device_id, session_factory, pattern_builder, timing=None, session=None, cfg=None, stack=None):
     """Rank 0 builds the connectivity tables of the mesh once and broadcasts them ("mesh/CSR pattern
-    from rank 0"); every session of every rank installs them.  Without a builder (tests that inject their own
+    from rank 0"); every other session of every rank installs them.  With ``session`` (rank 0's first solver session,
+    created without a pattern) the tables are the ones that session builds for its own resident problem of ``cfg`` -
+    no extra solver context, no second installation on rank 0.  Without a builder (tests that inject their own
     session factory and no builder) nothing is shared and each session builds its own."""
+    rank, _ = world_info()
+    t0 = time.perf_counter()
     if pattern_builder is None:
         if session_factory is not None:
             return None
-        pattern_builder = build_pattern_blob
-    rank, _ = world_info()
-    t0 = time.perf_counter()
+        if session is not None and rank == 0:
+            from .driver import suppress_output
+            with suppress_output(True):
+                session.prepare(cfg, stack)
+            pattern_builder = lambda *a: session.problem.backend.export_pattern()   # noqa: E731
+        else:
+            pattern_builder = build_pattern_blob
     blob = pattern_builder(*arrays, device_id) if rank == 0 else np.zeros(0, np.uint8)
     t1 = time.perf_counter()
     blob = broadcast_bytes(blob)
@@ -180,10 +208,76 @@ def shared_pattern(arrays, device_id, session_factory, pattern_builder, timing=N
     return blob
 
 
-def make_session(arrays, tag_map, device_id, session_factory, pattern):
+def make_session(arrays, tag_map, device_id, session_factory, pattern, hierarchy=None):
     if session_factory is not None:
-        return session_factory(*arrays, tag_map) if pattern is None else session_factory(*arrays, tag_map, pattern=pattern)
-    return SimulationSession(*arrays, tag_map, device_id=device_id, pattern=pattern)
+        kw = {}
+        if pattern is not None:
+            kw["pattern"] = pattern
+        if hierarchy is not None:
+            kw["hierarchy"] = hierarchy
+        return session_factory(*arrays, tag_map, **kw)
+    return SimulationSession(*arrays, tag_map, device_id=device_id, pattern=pattern, hierarchy=hierarchy)
+
+
+def _factory_takes_hierarchy(session_factory):
+    if session_factory is None:
+        return True
+    import inspect
+    try:
+        params = inspect.signature(session_factory).parameters
+    except (TypeError, ValueError):
+        return False
+    return "hierarchy" in params or any(p.kind == p.VAR_KEYWORD for p in params.values())
+
+
+def shared_hierarchy(session, cfg, stack, session_factory, timing=None):
+    """The multigrid hierarchy of the sweep's first configuration, built ONCE: rank 0's first session creates its resident
+    problem for ``cfg`` (tables, matrices, host set-up of the hierarchy) and exports the hierarchy; the blob is broadcast
+    like the connectivity tables (RCCL: device to device) and every other session of every rank installs it instead of
+    repeating the set-up (the reference's analogue: each pool worker factorises for itself, run_with_diamond.py:389-394).
+    Returns {"blob", "k"} for ``make_session(..., hierarchy=)``, or None when the sessions do not take one."""
+    if not _factory_takes_hierarchy(session_factory) or getattr(session, "precond", 1) != 1:
+        return None
+    rank, world = world_info()
+    t0 = time.perf_counter()
+    share = None
+    if rank == 0:
+        from .driver import suppress_output
+        with suppress_output(True):
+            session.prepare(cfg, stack)
+        share = session.export_hierarchy()
+    t1 = time.perf_counter()
+    if world > 1:
+        d = _dist()
+        box = [share["k"] if rank == 0 else None]
+        d.broadcast_object_list(box, 0)
+        blob = broadcast_bytes(share["blob"] if rank == 0 else np.zeros(0, np.uint8))
+        share = {"blob": blob, "k": box[0]}
+    if timing is not None:
+        timing["hierarchy_build_s"] = t1 - t0
+        timing["hierarchy_broadcast_s"] = time.perf_counter() - t1
+        timing["hierarchy_bytes"] = int(len(share["blob"]))
+    return share
+
+
+def warm_device(device_id, session_factory=None):
+    """Initialise the HIP runtime on this rank's GPU and load the library's kernels now (0.1-0.2 s the first time in a
+    process), on a thread of its own - while rank 0 meshes and the others wait for the mesh - instead of inside the first
+    solver session.  Returns the thread (join it before the first session is made), or None."""
+    if session_factory is not None:
+        return None
+    import threading
+
+    def init():
+        from .hip_backend import HeatflowHIP
+        try:
+            HeatflowHIP(device_id).close()
+        except Exception:            # noqa: BLE001 - the first real session reports what is wrong with the device
+            pass
+
+    th = threading.Thread(target=init, name="heatflow-warm-device", daemon=True)
+    th.start()
+    return th
 
 
 _EMPTY_MESH = (np.zeros((0, 2)), np.zeros((0, 3), np.int32), np.zeros(0, np.int32))
@@ -318,7 +412,11 @@ def run_parameter_sweep(base_config_path, output_dir, fwhm_range, k_range, width
             arrays = (coords, tris, tags)
         arrays, tag_map = broadcast_mesh(arrays, tag_map)
         pattern = shared_pattern(arrays, device_id, session_factory, pattern_builder)
-        session = make_session(arrays, tag_map, device_id, session_factory, pattern)
+        # the group's first configuration: hierarchy built once (rank 0) and installed by the other ranks' sessions
+        session = make_session(arrays, tag_map, device_id, session_factory, pattern) if rank == 0 else None
+        hierarchy = shared_hierarchy(session, cfg0, stack0, session_factory) if world > 1 else None
+        if session is None:
+            session = make_session(arrays, tag_map, device_id, session_factory, pattern, hierarchy)
         try:
             mine = [(done + idx + 1, combo) for idx, combo in shard(group, rank, world)]
             for items in batch_groups(mine, batch):
@@ -395,8 +493,9 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
     stack = build_stack(cfg)
     t_phase = time.perf_counter()
     arrays, tag_map = _EMPTY_MESH, None
+    warming = warm_device(device_id, session_factory)    # overlaps rank 0's meshing / the wait for the mesh
     if rank == 0:
-        coords, tris, tags, tag_map = prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack)
+        coords, tris, tags, tag_map = prepare_mesh(cfg, mesh_folder, rebuild_mesh, stack, defer_write=True)
         arrays = (coords, tris, tags)
         os.makedirs(output_dir, exist_ok=True)
     if timing is not None:
@@ -405,8 +504,25 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
     arrays, tag_map = broadcast_mesh(arrays, tag_map)
     if timing is not None:
         timing["broadcast_s"] = time.perf_counter() - t_phase
-    pattern = shared_pattern(arrays, device_id, session_factory, pattern_builder, timing)
-    session = make_session(arrays, tag_map, device_id, session_factory, pattern)
+        timing["t_mesh_received"] = time.perf_counter()
+        timing["n_dof"] = int(len(arrays[0]))
+    if warming is not None:
+        warming.join()
+    # the first configuration of the sweep: rank 0's first session builds its connectivity tables and its multigrid hierarchy;
+    # both are broadcast and installed by every other session of every rank
+    cfg_first = copy.deepcopy(cfg)
+    if len(k_values):
+        cfg_first["mats"]["p_sample"]["k"] = float(list(k_values)[0])
+    stack_first = build_stack(cfg_first)
+    first = pattern_builder is None and session_factory is None      # product path: the tables come from rank 0's own session
+    session = make_session(arrays, tag_map, device_id, session_factory, None) if (rank == 0 and first) else None
+    pattern = shared_pattern(arrays, device_id, session_factory, pattern_builder, timing, session=session, cfg=cfg_first, stack=stack_first)
+    t_phase = time.perf_counter()
+    if session is None and rank == 0:
+        session = make_session(arrays, tag_map, device_id, session_factory, pattern)
+    hierarchy = shared_hierarchy(session, cfg_first, stack_first, session_factory, timing)
+    if session is None:
+        session = make_session(arrays, tag_map, device_id, session_factory, pattern, hierarchy)
     exp = None
     if exp_csv is not None:
         exp = np.genfromtxt(exp_csv, delimiter=",", names=True)
@@ -470,7 +586,9 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
     try:
         n_sess = min(concurrent, len(mine)) if concurrent > 1 else 1
         for _ in range(max(n_sess, 1) - 1):
-            sessions.append(make_session(arrays, tag_map, device_id, session_factory, pattern))
+            sessions.append(make_session(arrays, tag_map, device_id, session_factory, pattern, hierarchy))
+        if timing is not None:
+            timing["session_s"] = time.perf_counter() - t_phase
         if warmup_steps > 0 and len(k_values):
             t_phase = time.perf_counter()
             cw = copy.deepcopy(cfg)
@@ -480,10 +598,17 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
             cw["mats"]["p_sample"]["k"] = float(list(k_values)[0])
             from .driver import suppress_output
             with suppress_output(True):
-                for sess in sessions:
-                    sess.run(cw, build_stack(cw), get_watcher_points(cw))
+                if len(sessions) > 1:                    # each session on its own thread: installs and first launches overlap
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(max_workers=len(sessions)) as pool:
+                        list(pool.map(lambda s: s.run(cw, build_stack(cw), get_watcher_points(cw)), sessions))
+                else:
+                    session.run(cw, build_stack(cw), get_watcher_points(cw))
             if timing is not None:
                 timing["warmup_s"] = time.perf_counter() - t_phase
+        if timing is not None:
+            timing["mesh_received_to_ready_s"] = time.perf_counter() - timing["t_mesh_received"]
+            del timing["t_mesh_received"]
         if on_ready is not None:
             on_ready()
         t_phase = time.perf_counter()
@@ -514,8 +639,13 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
             timing["batches"] = [len(ks) for ks in mine]
             timing["sessions"] = len(sessions)
     finally:
+        t_phase = time.perf_counter()
         for sess in sessions:
             sess.close()
+        flush_mesh_writes()
+        if timing is not None:
+            timing["close_s"] = time.perf_counter() - t_phase
+    t_phase = time.perf_counter()
     d = _dist()
     if d is not None and world > 1:
         gathered = [None] * world
@@ -524,6 +654,8 @@ def run_kappa_sweep(cfg, mesh_folder, k_values, output_dir, *, rebuild_mesh=Fals
     rows.sort(key=lambda r: r["k"])
     if rank == 0:
         _write_rows(os.path.join(output_dir, "rmse_summary.csv"), rows)
+    if timing is not None:
+        timing["gather_write_s"] = time.perf_counter() - t_phase
     return rows
 
 

@@ -14,7 +14,6 @@ from __future__ import annotations
 import time
 
 import numpy as np
-from scipy.spatial import cKDTree
 
 from .bc import gather_bc_values, gather_plan, merge_bcs
 from .hip_backend import ASM_ROW_GATHER, PC_AMG, PC_JACOBI, HeatflowHIP
@@ -41,13 +40,15 @@ class HeatProblem:
               ASM_LDS_COLORED (LDS scatter by colours, reproducible), ASM_LDS_ATOMIC (LDS atomics, diagonals
               summed in arrival order) or ASM_GLOBAL_ATOMIC (baseline)
     pattern : connectivity tables exported by another context on the same mesh (HeatflowHIP.export_pattern)
+    amg : multigrid hierarchy exported by another context on the same mesh (HeatflowHIP.amg_export; needs precond=PC_AMG
+              and amg_reuse=True): installed instead of being built
     precond : PC_JACOBI (Jacobi-PCG, the north-star solver) or PC_AMG (PCG preconditioned by a
               smoothed-aggregation V-cycle: same stopping rule and answer, ~50x fewer iterations)
     """
 
     def __init__(self, coords, tris, tags, tag_to_k, tag_to_rho_cv, dt, bcs, u0, *, backend=None, device_id=0,
                  assembly_mode=ASM_ROW_GATHER, rtol=DEFAULT_RTOL, atol=0.0, max_it=DEFAULT_MAX_IT,
-                 precond=PC_JACOBI, amg_reuse=False, pattern=None):
+                 precond=PC_JACOBI, amg_reuse=False, pattern=None, amg=None):
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.n = self.coords.shape[0]
         self.dt = float(dt)
@@ -72,6 +73,8 @@ class HeatProblem:
             self._owner = self._pos = np.zeros(0, dtype=np.int64)
         self.backend.set_dirichlet(self.bc_dofs)
         self.backend.set_precond(precond, amg_reuse)
+        if amg is not None and precond == PC_AMG and amg_reuse:
+            self.backend.amg_install(amg)
         self.backend.assemble(self.dt, self.assembly_mode)
         u = np.full(self.n, float(u0)) if np.isscalar(u0) else np.asarray(u0, dtype=np.float64)
         self.backend.set_state(u)
@@ -131,7 +134,12 @@ class HeatProblem:
 
 
 def nearest_nodes(coords, points):
-    """Nearest mesh node of each (z, r) point (cKDTree on the 2-D node coordinates, as
-    run_with_diamond.py:443-449)."""
-    tree = cKDTree(np.asarray(coords)[:, :2])
-    return np.array([tree.query(p)[1] for p in points], dtype=np.int32)
+    """Nearest mesh node of each (z, r) point (run_with_diamond.py:443-449 asks a cKDTree over geometry.x[:, :2] for it).
+    A handful of watcher points does not repay a tree over the whole mesh (60 ms to build at 2e5 nodes, plus the import of
+    scipy.spatial): one pass of squared distances per point; of equidistant nodes the lowest-numbered one is taken."""
+    xy = np.asarray(coords, dtype=np.float64)[:, :2]
+    out = np.empty(len(points), dtype=np.int32)
+    for q, p in enumerate(points):
+        dz, dr = xy[:, 0] - float(p[0]), xy[:, 1] - float(p[1])
+        out[q] = int(np.argmin(dz * dz + dr * dr))
+    return out

@@ -138,6 +138,20 @@ int hf_set_precond(hf_ctx* ctx, int32_t kind, int32_t reuse);
 int hf_get_amg_info(hf_ctx* ctx, int32_t* n_levels, int32_t* level_rows, int32_t max_levels, double* op_complexity,
                     double* setup_seconds);
 
+/* The hierarchy of a context as one blob, for other contexts on the same mesh (the other sessions of a sweep, on this
+ * GPU or - broadcast with the mesh - on the other ranks): what the host set-up computes is shipped instead of recomputed.
+ * The reference's analogue is the per-worker MUMPS factorisation (run_with_diamond.py:389-394; every pool worker of
+ * parameter_sweep.py:401-446 factorises for itself).  hf_amg_export needs a completed hf_assemble with the multigrid
+ * preconditioner; blob = host or device memory of hf_amg_export_size bytes.  hf_amg_install needs hf_set_mesh,
+ * hf_set_dirichlet and hf_set_precond(1, reuse = 1) on the same mesh and is followed by hf_assemble, which keeps the
+ * installed hierarchy instead of building one and compares its own operator with the fingerprint in the blob (time step,
+ * coefficient tables, Dirichlet set): the same operator -> the cycle is the one the exporting context runs, bit for bit;
+ * another point of a sweep -> the hierarchy is a frozen one (see hf_set_precond).  Every index in the blob is
+ * verified; HF_ERR_ARG if it does not belong to this mesh. */
+int hf_amg_export_size(hf_ctx* ctx, int64_t* bytes);
+int hf_amg_export(hf_ctx* ctx, void* blob, int64_t bytes);
+int hf_amg_install(hf_ctx* ctx, const void* blob, int64_t bytes);
+
 /* Start vector of every hf_step / hf_run solve (the converged answer does not depend on it, only the
  * iteration count does): kind 0 = u^n (what KSP.solve sees in the reference, run_with_diamond.py:480,
  * where it is irrelevant because the solve is direct); 1 = 2 u^n - u^{n-1}; 2 = that plus the

@@ -40,6 +40,17 @@ class OracleBackend:
         self.u = np.zeros(self.n)
         self.set_mesh_calls += 1
 
+    # -- hierarchy hand-over stand-in (hf_amg_export / hf_amg_install): the oracle has no hierarchy, the calls are recorded
+    def amg_export(self, into=None):
+        self.amg_export_calls = getattr(self, "amg_export_calls", 0) + 1
+        return np.frombuffer(b"FAKEAMG!" + np.int64(self.n).tobytes(), dtype=np.uint8).copy()
+
+    def amg_install(self, blob):
+        b = np.asarray(blob, dtype=np.uint8).tobytes()
+        if b[:8] != b"FAKEAMG!" or np.frombuffer(b[8:16], dtype=np.int64)[0] != self.n:
+            raise ValueError("hierarchy blob does not belong to this mesh")
+        self.amg_install_calls = getattr(self, "amg_install_calls", 0) + 1
+
     def set_materials(self, tags, kappa, rho_c):
         self.tag_to_k = {int(t): float(k) for t, k in zip(tags, kappa)}
         self.tag_to_rc = {int(t): float(c) for t, c in zip(tags, rho_c)}

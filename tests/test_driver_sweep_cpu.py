@@ -118,6 +118,12 @@ def _session_factory(coords, tris, tags, tag_map, pattern=None):
     return SimulationSession(coords, tris, tags, tag_map, backend=OracleBackend(), pattern=pattern)
 
 
+def _sharing_session_factory(coords, tris, tags, tag_map, pattern=None, hierarchy=None):
+    """As above, and takes the sweep's shared multigrid hierarchy (parameter_sweep.shared_hierarchy)."""
+    from heatflow_amd.driver import SimulationSession
+    return SimulationSession(coords, tris, tags, tag_map, backend=OracleBackend(), pattern=pattern, hierarchy=hierarchy)
+
+
 def test_sweep_single_process_writes_artefacts_and_failed_rows(tmp_path):
     cfg = _cfg("geballe_no_diamond", 16.0, 6)
     cfg_path = str(tmp_path / "base.yaml")
@@ -212,18 +218,21 @@ KAPPA_WORKER = textwrap.dedent("""
     sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
     import torch.distributed as dist
     from heatflow_amd import parameter_sweep as ps
-    from test_driver_sweep_cpu import _session_factory
+    from test_driver_sweep_cpu import _sharing_session_factory
     from oracle_backend import fake_pattern_blob
     dist.init_process_group("gloo")
     cfg = yaml.safe_load(open({cfg!r}))
     timing = {{}}
-    made = []
+    made, sessions = [], []
     def factory(*a, **kw):
         made.append(kw.get("pattern") is not None)
-        return _session_factory(*a, **kw)
+        sessions.append(_sharing_session_factory(*a, **kw))
+        return sessions[-1]
     rows = ps.run_kappa_sweep(cfg, {mesh!r}, [3.3, 3.6, 3.9, 4.2], {out!r}, session_factory=factory,
                               concurrent=2, warmup_steps=2, timing=timing, pattern_builder=fake_pattern_blob)
     timing["sessions_with_pattern"] = sum(made)
+    timing["hierarchy_exports"] = [getattr(s.backend, "amg_export_calls", 0) for s in sessions]
+    timing["hierarchy_installs"] = [getattr(s.backend, "amg_install_calls", 0) for s in sessions]
     gathered = [None, None]
     dist.all_gather_object(gathered, timing)
     timing = {{"rank0": gathered[0], "rank1": gathered[1], **gathered[0]}}
@@ -275,6 +284,11 @@ def test_kappa_sweep_world_size_2_uses_rank0s_tag_map_for_a_cached_mesh(tmp_path
     # the connectivity tables: built by rank 0 only, broadcast, installed by every session of both ranks
     for r in ("rank0", "rank1"):
         assert got["timing"][r]["sessions_with_pattern"] == 2 and got["timing"][r]["pattern_bytes"] == 28
+    # the multigrid hierarchy: built and exported by rank 0's first session only, broadcast, installed by its second session and
+    # by both sessions of rank 1 - no other session runs the host set-up
+    assert got["timing"]["rank0"]["hierarchy_exports"] == [1, 0] and got["timing"]["rank0"]["hierarchy_installs"] == [0, 1]
+    assert got["timing"]["rank1"]["hierarchy_exports"] == [0, 0] and got["timing"]["rank1"]["hierarchy_installs"] == [1, 1]
+    assert got["timing"]["rank1"]["hierarchy_bytes"] == 16 and got["timing"]["rank1"]["mesh_received_to_ready_s"] > 0
     for r in got["rows"]:
         a = np.genfromtxt(os.path.join(str(tmp_path / "out1"), f"{r['k']:.2f}", "watcher_points.csv"), delimiter=",", names=True)
         b = np.genfromtxt(os.path.join(str(tmp_path / "out2"), f"{r['k']:.2f}", "watcher_points.csv"), delimiter=",", names=True)

@@ -1114,6 +1114,108 @@ def test_mesh_read_through_the_msh41_reader_runs_on_hip_and_matches_the_oracle(h
         prob.close()
 
 
+def test_hierarchy_export_and_install_give_a_bit_identical_time_loop(hip):
+    """hf_amg_export / hf_amg_install: the multigrid hierarchy one context built is installed by another on the same mesh
+    (host blob, and a blob in device memory as an RCCL broadcast leaves it) instead of repeating the host set-up.
+    Same operator -> the same cycle, bit for bit (fields and iteration counts of a time loop, single and batched);
+    another point of a kappa sweep -> the installed hierarchy is a frozen one: same answer to solver tolerance.
+    Damaged blobs and blobs of another mesh are refused."""
+    import copy
+    import ctypes as C
+    from conftest import build_case
+
+    cfg, stack, mesh = build_case("geballe_with_diamond", 2.0)
+    assert len(mesh.coords) > 30000
+
+    def loop(prob, nsteps=10):
+        for bc in prob.bcs:
+            bc.update(0.0)
+        for k in range(nsteps):
+            prob.step((k + 1) * prob.dt, only=[prob.bcs[3]])
+        return prob.state(), list(prob.iters)
+
+    a = make_problem(cfg, stack, mesh, precond=1, amg_reuse=True)
+    try:
+        info_a = a.backend.amg_info()
+        assert info_a["levels"] >= 3
+        blob = a.backend.amg_export()
+        assert blob.dtype == np.uint8 and bytes(blob[:6]) == b"HFAMG0"
+        ua, ita = loop(a)
+    finally:
+        a.close()
+    b = make_problem(cfg, stack, mesh, precond=1, amg_reuse=True, amg=blob)
+    try:
+        info_b = b.backend.amg_info()
+        assert info_b["rows"] == info_a["rows"] and info_b["op_complexity"] == info_a["op_complexity"]
+        assert np.array_equal(b.backend.amg_export(), blob)          # and exports the same blob again
+        ub, itb = loop(b)
+        assert itb == ita and np.array_equal(ub, ua) and max(ita) >= 4
+    finally:
+        b.close()
+    # the blob in device memory, read from there by address
+    rt = hip.load_library()
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    d_in = C.c_void_p()
+    assert rt.hipMalloc(C.byref(d_in), blob.nbytes) == 0
+    try:
+        assert rt.hipMemcpy(d_in, C.c_void_p(blob.ctypes.data), blob.nbytes, 1) == 0
+        c = make_problem(cfg, stack, mesh, precond=1, amg_reuse=True, amg=(d_in.value, blob.nbytes))
+        try:
+            uc, itc = loop(c)
+            assert itc == ita and np.array_equal(uc, ua)
+        finally:
+            c.close()
+    finally:
+        rt.hipFree(d_in)
+    # another point of a sweep: kappa_sample 3.8 -> 4.3 under the hierarchy built for 3.8 = what the context does itself when
+    # it keeps its levels (frozen hierarchy): bit-identical to that, and equal to a hierarchy of its own within the tolerance
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["mats"]["p_sample"]["k"] = 4.3
+    from heatflow_amd.geometry import build_stack
+    stack2 = build_stack(cfg2)
+    own = make_problem(cfg2, stack2, mesh, precond=1, amg_reuse=True)
+    try:
+        u_own, it_own = loop(own)
+    finally:
+        own.close()
+    kept = make_problem(cfg, stack, mesh, precond=1, amg_reuse=True)
+    try:
+        tk, trc = material_tables(stack2, mesh)
+        kept.set_materials(tk, trc)
+        u_kept, it_kept = loop(kept)
+    finally:
+        kept.close()
+    inst = make_problem(cfg2, stack2, mesh, precond=1, amg_reuse=True, amg=blob)
+    try:
+        u_inst, it_inst = loop(inst)
+    finally:
+        inst.close()
+    assert it_inst == it_kept and np.array_equal(u_inst, u_kept)
+    assert np.abs(u_inst - u_own).max() <= 1e-5 and max(it_inst) <= max(it_own) + 4
+    # refused
+    small = build_case("geballe_with_diamond", 8.0)
+    with pytest.raises(ValueError, match="this mesh has"):
+        make_problem(small[0], small[1], small[2], precond=1, amg_reuse=True, amg=blob).close()
+    bad = blob.copy(); bad[0] ^= 1
+    with pytest.raises(ValueError, match="not a hierarchy blob"):
+        make_problem(cfg, stack, mesh, precond=1, amg_reuse=True, amg=bad).close()
+    with pytest.raises(ValueError, match="bytes"):
+        make_problem(cfg, stack, mesh, precond=1, amg_reuse=True, amg=blob[:-16]).close()
+    hdr = 8 + 16 + 8 * 4 + 16 + 8                        # AmgBlobHeader; the coefficient tables and level 0 follow
+    bad = blob.copy()
+    words = bad[(hdr + 15) // 16 * 16:].view(np.int32)
+    # first operator's column indices lie somewhere behind the tables: corrupt a large run of int32 words to out-of-range values
+    words[4096:4096 + 64] = 2 ** 30
+    with pytest.raises(ValueError, match="hf_amg_install"):
+        make_problem(cfg, stack, mesh, precond=1, amg_reuse=True, amg=bad).close()
+    with hip.HeatflowHIP(0) as e:
+        e.set_mesh(mesh.coords, mesh.tris, mesh.tags)
+        with pytest.raises(hip.HipError, match="reuse = 1"):
+            e.amg_install(blob)
+
+
 def test_pattern_blob_export_and_prebuilt_install(hip, case_with_diamond_small):
     """hf_pattern_export / hf_set_mesh_prebuilt: the connectivity tables one context built are installed by another
     (host blob, and a blob held in device memory as an RCCL broadcast leaves it); matrices, lazily built scatter
