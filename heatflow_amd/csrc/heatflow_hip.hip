@@ -455,18 +455,28 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
     const double d = (p1[0] - p0[0]) * (p2[1] - p0[1]) - (p2[0] - p0[0]) * (p1[1] - p0[1]);
     if (!(d != 0.0)) return fail(ctx, HF_ERR_ARG, "hf_set_mesh: degenerate triangle %d", e);
   }
+  const auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (std::getenv("HEATFLOW_DEBUG")) std::fprintf(stderr, "[set_mesh] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  };
+  lap("checked");
   MeshTables T;
   Pattern P;
   HF_TRY(build_csr(ctx, n, ne, tri, P));
+  lap("+ csr pattern");
   build_rowgather(n, ne, tri, tag, P);
+  lap("+ row-gather lists");
   if (!build_coldict(P.rowptr, P.colidx, n, TS, T.spmv)) return fail(ctx, HF_ERR_ARG, "an SpMV chunk touches more than 65535 columns (16-bit positions)");
+  lap("+ spmv column lists");
   T.rowptr.swap(P.rowptr);
   T.colidx.swap(P.colidx);
   T.max_blk_nnz = P.max_blk_nnz;
   T.rg = std::move(P.rg);
   T.tag_used.assign(static_cast<size_t>(maxtag) + 1, 0);
   for (int32_t e = 0; e < ne; ++e) T.tag_used[tag[e]] = 1;
-  return install_mesh(ctx, n, ne, zr, tri, tag, T);
+  const int rc = install_mesh(ctx, n, ne, zr, tri, tag, T);
+  lap("+ installed");
+  return rc;
 }
 
 int hf_set_mesh_prebuilt(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int32_t* tri, const int32_t* tag,

@@ -595,6 +595,20 @@ __device__ __forceinline__ void mirror_breakdown(ScalMirror* m, unsigned epoch) 
 // column list, so the row-wise operand x[row] of MODE 4 / 8 / 9 is taken from the staged slice instead of read again.
 struct ColComp { const int32_t* dptr; const int32_t* dict; const uint16_t* id; int xd_off; int own; };
 
+// The matrix stream (values, 16-bit positions) is read exactly once per launch: HF_NT_STREAM=1 marks those loads non-temporal
+// (A/B builds; 0 = plain loads)
+#ifndef HF_NT_STREAM
+#define HF_NT_STREAM 0
+#endif
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#if HF_NT_STREAM
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 template <int MODE, bool C16 = false, typename VT = double>
 __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows per chunk, <= TS */,
                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
@@ -687,8 +701,8 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
 #pragma unroll
       for (int u = 0; u < HF_UNROLL; ++u) {
         const bool in = k + u * TS < k1;
-        v[u] = in ? static_cast<double>(vals[k + u * TS]) : 0.0;
-        id[u] = in ? static_cast<int>(comp.id[k + u * TS]) : 0;
+        v[u] = in ? static_cast<double>(stream_load(&vals[k + u * TS])) : 0.0;
+        id[u] = in ? static_cast<int>(stream_load(&comp.id[k + u * TS])) : 0;
       }
       // HF_STAGE_U entries of the column list per lane and pass (the fine operator's lists hold 1.3 TS entries, those of the
       // transfer operators up to 3.5 TS): the list loads go out together and the gathers after them - dependent round
@@ -716,8 +730,8 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
 #pragma unroll
         for (int u = 0; u < HF_UNROLL; ++u) {
           const bool in = kn + u * TS < k1;
-          vn[u] = in ? static_cast<double>(vals[kn + u * TS]) : 0.0;
-          idn[u] = in ? static_cast<int>(comp.id[kn + u * TS]) : 0;
+          vn[u] = in ? static_cast<double>(stream_load(&vals[kn + u * TS])) : 0.0;
+          idn[u] = in ? static_cast<int>(stream_load(&comp.id[kn + u * TS])) : 0;
         }
 #pragma unroll
         for (int u = 0; u < HF_UNROLL; ++u)

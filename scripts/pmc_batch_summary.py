@@ -7,6 +7,7 @@ FETCH_SIZE; calibrated on the vector kernels).  n and nnz default to the `n = ..
 prints (its log sits next to the PMC directories).  Algorithmic bytes (SURVEY 8d conventions: f64 values, i32 indices,
 every array once per pass) for the affine operator family A_j = A + d_j A1 on NV interleaved columns:
   kb_spmv<9>  (4 + 16)*nnz + 4*n + 40*n*NV   colidx + two value arrays; rowptr; per row and column z (8), Ap and p read-modify-write (32)
+              (kb_spmv_lds, the LDS-staged kernel with 16-bit column positions, is held to the same i32-index formula)
   kb_spmv<4>  (4 + 16)*nnz + 4*n + 32*n*NV   z, b, dinv read, z2 written
   kb_spmv<3>  (4 + 16)*nnz + 4*n + 24*n*NV   z, b read, tmp written
   kb_spmv<0>  (4 + 8)*nnz  + 4*n + 16*n*NV   right-hand side b = M u (shared values)
@@ -28,7 +29,7 @@ def short(name):
     if not m:
         return name[:30]
     targs = (m.group(2) or "").replace(" ", "")
-    if m.group(1) == "kb_spmv":
+    if m.group(1) in ("kb_spmv", "kb_spmv_lds"):
         targs = re.sub(r"^<(\d+),(\d+),(\d+)(,.*)?>$", lambda q: f"<{q.group(1)},nv{q.group(2)},op{q.group(3)}{q.group(4) or ''}>", targs)
     return m.group(1) + targs
 
@@ -43,7 +44,7 @@ for kind, d in (("fetch", fetch_dir), ("write", write_dir)):
 
 
 def algorithmic(k):
-    m = re.match(r"kb_spmv<(\d+),nv(\d+),op(\d+)", k)
+    m = re.match(r"kb_spmv(?:_lds)?<(\d+),nv(\d+),op(\d+)", k)
     if m:
         mode, v, op = int(m.group(1)), int(m.group(2)), int(m.group(3))
         mat = {0: 12, 1: 4 + 8 * v, 2: 20}[op] * nnz + 4 * n
