@@ -17,7 +17,7 @@ refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
   broadcasts over RCCL together with its tag map; no data-path collective.  value = all ranks' DOF-updates /
   max-over-ranks time ("weak" scaling).
 * workload ``sweep64`` (BASELINE C5): 64 kappa_sample values (parameter_sweep.get_k_values(count=64)) at stock
-  mesh size, point i -> rank i mod world, batches of 8 points per time loop (hf_batch_*), 2 loops in flight per rank; K = time steps per point (default: the
+  mesh size, point i -> rank i mod world, batches of up to 16 points per time loop (hf_batch_*), 2 loops in flight per rank; K = time steps per point (default: the
   config's 100), W = untimed steps every solver session runs first.  value = 64*n*K / wall of the point loop
   (max over ranks), "strong" scaling (the 64 points are fixed).  The same sweep is also run as a side
   measurement of the default workload (``config.sweep64``; ``--sweep-points 0`` skips it).
@@ -37,7 +37,7 @@ refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
   its points over ``mp.Pool(processes=mp.cpu_count())`` (parameter_sweep.py:389-390, 423-446); the round-2 figure (8 points
   on 8 cores) is kept beside it (``cpu_farm_8_points``).  Both run in child processes before this one touches the GPU.
 * roofline of workload sweep64 (``config.sweep64.roofline`` of the default one): the batched loop's iteration head
-  kb_spmv_lds<9> (8 columns, affine operator family), in-loop events on one batch of 8 at stock size, and the same kernel
+  kb_spmv_lds<9> (16 columns, affine operator family), in-loop events on one batch of 16 at stock size, and the same kernel
   on the 1M-DOF mesh, where the batch's vectors (66 MB each) are far beyond the Infinity Cache (``hbm_resident``).
 """
 import os
@@ -60,8 +60,9 @@ TARGET_DOF = 1.0e6
 MESH_SCALE = 0.43          # all `mesh:` values x 0.43 -> 1.04 M nodes (within +-5 % of 1.0e6)
 HBM_SCALE = 0.1075         # -> 16 M nodes: matrix 1.3 GB, vectors 128 MB each, nothing stays in the 256 MiB Infinity Cache
 SWEEP_POINTS = 64          # BASELINE C5
-SWEEP_BATCH = 8            # points per batched time loop (hf_batch_*): columns of one multi-vector PCG
-SWEEP_CONCURRENT = 2       # time loops in flight per rank (64 points on one GPU in batches of 8: 1 / 2 in flight = 7.1 / 9.0e8 DOF-updates/s; unbatched, 6 in flight: 4.5e8)
+SWEEP_BATCH = 16           # points per batched time loop (hf_batch_*): columns of one multi-vector PCG; a rank with fewer points takes 8 / 4 / 2
+SWEEP_CONCURRENT = 2       # time loops in flight per rank (64 points on one GPU, round 3: batches of 16, 1 / 2 in flight = 1.09 / 1.20e9 DOF-updates/s;
+                           # batches of 8: 0.90 / 1.08e9; round 2, batches of 8: 7.1 / 9.0e8; unbatched, 6 in flight: 4.5e8)
 
 
 def parse_args(argv=None):

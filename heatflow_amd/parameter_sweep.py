@@ -672,7 +672,7 @@ def main(argv=None):
     p.add_argument("--mesh-folder", default="meshes")
     p.add_argument("--write-xdmf", action="store_true")
     p.add_argument("--verbose", action="store_true")
-    p.add_argument("--batch", type=int, default=8,
+    p.add_argument("--batch", type=int, default=16,
                    help="points of a rank advanced together by the batched time loop (16, 8, 4, 2; 1 = one run per point)")
     a = p.parse_args(argv)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:

@@ -11,7 +11,7 @@ for v in "$@"; do
   i=$((i+1))
   D=$O/trace_${tag}_$i
   for kv in $v; do export "$kv"; done
-  timeout -k 10 300 rocprofv3 --kernel-trace -d $D -o run --output-format csv -- python3 $R/scripts/batch_probe.py 1.0 8 30 1 > $O/trace_${tag}_$i.log 2>&1 || { echo "variant '$v' failed"; tail -5 $O/trace_${tag}_$i.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace -d $D -o run --output-format csv -- python3 $R/scripts/batch_probe.py 1.0 ${NV:-8} 30 1 > $O/trace_${tag}_$i.log 2>&1 || { echo "variant '$v' failed"; tail -5 $O/trace_${tag}_$i.log; exit 1; }
   for kv in $v; do unset "${kv%%=*}"; done
   echo "== ${v:-(default)}"
   python3 $R/scripts/batch_breakdown.py $(find $D -name 'run_kernel_trace.csv' | head -1)

@@ -247,7 +247,7 @@ def test_c4_two_sided_heating_extension_at_stock_size(hip, c2):
 
 
 def test_c5_sixty_four_point_kappa_sweep_on_one_gpu(hip, tmp_path):
-    """BASELINE C5 at its stated size on one GPU, as bench.py runs it (a world of 1 takes all 64 points: batches of 8
+    """BASELINE C5 at its stated size on one GPU, as bench.py runs it (a world of 1 takes all 64 points: batches of 16
     through the batched time loop, 2 loops in flight): 64 kappa_sample values on the stock geballe_with_diamond mesh,
     100 steps each (reference parameter_sweep.py:423-446, sweep_test.py:47-115).  Every point must succeed; three of
     them (both ends and the middle of the grid) are re-run by the oracle on the same mesh and compared at every step."""
@@ -266,10 +266,10 @@ def test_c5_sixty_four_point_kappa_sweep_on_one_gpu(hip, tmp_path):
     assert len(ks) == 64 and len({f"{k:.2f}" for k in ks}) == 64
     mesh_folder, out = str(tmp_path / "mesh"), str(tmp_path / "out")
     timing = {}
-    rows = ps.run_kappa_sweep(cfg, mesh_folder, ks, out, rebuild_mesh=True, concurrent=2, batch=8, exp_csv=HEATING_CSV, timing=timing)
+    rows = ps.run_kappa_sweep(cfg, mesh_folder, ks, out, rebuild_mesh=True, concurrent=2, batch=16, exp_csv=HEATING_CSV, timing=timing)
     assert len(rows) == 64 and all(r["status"] == "success" for r in rows), [r["error"] for r in rows if r["error"]][:1]
-    assert [r["k"] for r in rows] == sorted(ks.tolist()) and timing["sessions"] == 2 and timing["batches"] == [8] * 8
-    assert all(r.get("batch") == 8 and not r.get("batch_error") for r in rows)
+    assert [r["k"] for r in rows] == sorted(ks.tolist()) and timing["sessions"] == 2 and timing["batches"] == [16] * 4
+    assert all(r.get("batch") == 16 and not r.get("batch_error") for r in rows)
     assert all(np.isfinite(r["rmse"]) and 0.0 < r["rmse"] < 0.2 for r in rows)
     coords, tris, tags = load_mesh_arrays(os.path.join(mesh_folder, "mesh.msh"))
     mtags = yaml.safe_load(open(os.path.join(mesh_folder, "mesh_cfg.yaml")))["material_tags"]
