@@ -275,7 +275,16 @@ struct Params {
   double theta_level[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // > 0: threshold of that level (study)
   double theta_coarse = 0.0;    // > 0: strength threshold of every level below the finest
   bool attach_weak = false;     // aggregate(): rows without a strong coupling join the aggregate of their largest coupling
+  // A0 is the operator of global level `level_offset` of a hierarchy whose finer levels were built elsewhere (on the GPU,
+  // hf_amg_gpu.hpp): thresholds, fused legs and the ownership of levels[0].A follow the global level index
+  int level_offset = 0;
 };
+
+inline double level_theta(const Params& prm, int glev) {
+  double t = (glev > 0 && prm.theta_coarse > 0.0) ? prm.theta_coarse : prm.theta * std::pow(prm.theta_decay, glev);
+  if (glev < 8 && prm.theta_level[glev] > 0.0) t = prm.theta_level[glev];
+  return t;
+}
 
 // Build from the fine operator A0 (moved in; released after the first Galerkin product).
 inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
@@ -284,6 +293,7 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
   const double nnz0 = static_cast<double>(A.nnz());
   double nnz_sum = nnz0;
   for (int lev = 0;; ++lev) {
+    const int glev = lev + prm.level_offset;
     Level L;
     std::vector<double> d = diagonal(A);
     for (double v : d)
@@ -292,18 +302,17 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
     for (size_t i = 0; i < d.size(); ++i) L.dinv[i] = 1.0 / d[i];
     const double rho = gershgorin_rho(A, d);
     L.omega = prm.smooth_scale * 4.0 / (3.0 * rho);
-    const bool last = A.nrow <= prm.coarse_size || lev + 1 >= prm.max_levels;
+    const bool last = A.nrow <= prm.coarse_size || glev + 1 >= prm.max_levels;
     if (!last) {
       std::vector<int> agg;
-      double theta_l = (lev > 0 && prm.theta_coarse > 0.0) ? prm.theta_coarse : prm.theta * std::pow(prm.theta_decay, lev);
-      if (lev < 8 && prm.theta_level[lev] > 0.0) theta_l = prm.theta_level[lev];
+      const double theta_l = level_theta(prm, glev);
       const int na = aggregate(A, d, theta_l, agg, prm.attach_weak);
       if (prm.verbose) {
         int64_t none = 0, trivial = 0;
         for (int i = 0; i < A.nrow; ++i) {
           if (agg[i] < 0) { ++none; if (A.ptr[i + 1] - A.ptr[i] <= 1) ++trivial; }
         }
-        std::fprintf(stderr, "[amg setup] level %d rows %d aggregates %d (ratio %.2f) without aggregate %lld (of which identity rows %lld) theta %.4f\n", lev, A.nrow, na,
+        std::fprintf(stderr, "[amg setup] level %d rows %d aggregates %d (ratio %.2f) without aggregate %lld (of which identity rows %lld) theta %.4f\n", glev, A.nrow, na,
                      static_cast<double>(A.nrow) / std::max(na, 1), static_cast<long long>(none), static_cast<long long>(trivial), theta_l);
       }
       if (na == 0 || na > 0.8 * A.nrow) {            // coarsening stalled: finish here
@@ -313,7 +322,7 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
       }
       const auto tp0 = std::chrono::steady_clock::now();
       auto lap = [&](const char* what) {
-        if (prm.verbose) std::fprintf(stderr, "[amg setup] level %d %-22s %.3f s\n", lev, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count());
+        if (prm.verbose) std::fprintf(stderr, "[amg setup] level %d %-22s %.3f s\n", glev, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count());
       };
       L.P = smoothed_prolongator(A, d, agg, na, prm.prolong_scale * 4.0 / (3.0 * rho));
       for (int s = 1; s < prm.prolong_steps; ++s) L.P = smoothed_by_product(L.P, spgemm(A, L.P), L.dinv, prm.prolong_scale * 4.0 / (3.0 * rho));
@@ -324,13 +333,13 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
       lap("+ A P");
       Csr Ac = spgemm(L.R, AP);
       lap("+ R (A P)");
-      if (lev > 0 || prm.fuse_fine) {                // fused legs of the cycle (intermediate levels; the finest on request)
+      if (glev > 0 || prm.fuse_fine) {               // fused legs of the cycle (intermediate levels; the finest on request)
         const Csr Pt = smoothed_by_product(L.P, AP, L.dinv, L.omega);
         L.Rt = transpose(Pt);
-        if (lev > 0 || !prm.fuse_fine_down_only) L.GP = fused_up_leg(A, L.dinv, L.omega, Pt);
+        if (glev > 0 || !prm.fuse_fine_down_only) L.GP = fused_up_leg(A, L.dinv, L.omega, Pt);
       }
       lap("+ fused legs");
-      if (lev > 0) L.A = std::move(A);               // level 0's operator stays with the caller
+      if (glev > 0) L.A = std::move(A);              // level 0's operator stays with the caller
       H.levels.push_back(std::move(L));
       A = std::move(Ac);
       nnz_sum += static_cast<double>(A.nnz());
@@ -343,7 +352,7 @@ inline bool build(Csr&& A0, const Params& prm, Hierarchy& H) {
   const Csr& Ac = H.levels.back().A;
   H.coarse_n = Ac.nrow;
   H.op_complexity = nnz_sum / nnz0;
-  if (H.levels.size() == 1) H.coarse_n = 0;  // no coarsening possible: plain Jacobi
+  if (H.levels.size() == 1 && prm.level_offset == 0) H.coarse_n = 0;  // no coarsening possible: plain Jacobi
   return true;                               // the dense inverse of the coarsest operator is formed on the device
 }
 

@@ -601,7 +601,7 @@ int hf_assemble(hf_ctx* ctx, double dt, int32_t mode) {
     OperatorPrint now;
     HF_TRY(operator_print(ctx, now));
     if (!(ctx->amg_ready && ctx->amg_reuse)) {
-      HF_TRY(build_amg(ctx));
+      HF_TRY(build_amg_auto(ctx));
       ctx->amg_print = std::move(now);
     } else {
       // hierarchy kept (reuse) or installed from another context (hf_amg_install): its fused fine-level operators hold the

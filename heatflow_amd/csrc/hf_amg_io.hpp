@@ -8,6 +8,7 @@
 // knows whether its own operator is that one (fused finest-level legs usable) or another point of the sweep (frozen
 // hierarchy: explicit legs on the finest level until the next rebuild).
 #pragma once
+#include "hf_amg_gpu.hpp"
 #include "hf_batch.hpp"
 
 namespace {

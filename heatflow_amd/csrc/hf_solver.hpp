@@ -108,20 +108,9 @@ int wire_levels(hf_ctx* ctx) {
   return HF_OK;
 }
 
-// Build the hierarchy from the assembled, eliminated fine operator (download -> host set-up -> upload).
-int build_amg(hf_ctx* ctx) {
-  const auto t0 = std::chrono::steady_clock::now();
-  free_amg(ctx);
-  amg::Csr A0;
-  A0.nrow = A0.ncol = ctx->n;
-  A0.ptr.assign(ctx->h_rowptr.begin(), ctx->h_rowptr.end());
-  A0.idx.assign(ctx->h_colidx.begin(), ctx->h_colidx.end());
-  A0.val.resize(ctx->nnz);
-  HF_HIP(copy_sync(ctx, A0.val.data(), ctx->d_A, sizeof(double) * ctx->nnz, hipMemcpyDeviceToHost));
+// Set-up parameters: defaults of amg_host.hpp, the study knobs of the environment, and the form of the finest level.
+void amg_params(hf_ctx* ctx, amg::Params& prm) {
   if (const char* e = std::getenv("HEATFLOW_AMG_F32")) ctx->amg_f32 = (e[0] != '0');
-  const bool f32 = ctx->amg_f32;
-  amg::Hierarchy H;
-  amg::Params prm;
   if (const char* e = std::getenv("HEATFLOW_AMG_THETA")) prm.theta = std::atof(e);          // tuning knobs
   if (const char* e = std::getenv("HEATFLOW_AMG_COARSE")) prm.coarse_size = std::atoi(e);
   if (const char* e = std::getenv("HEATFLOW_AMG_THETA_COARSE")) prm.theta_coarse = std::atof(e);
@@ -139,27 +128,22 @@ int build_amg(hf_ctx* ctx) {
   if (const char* e = std::getenv("HEATFLOW_AMG_FUSE0")) ctx->amg_fuse0 = std::atoi(e);
   prm.fuse_fine = ctx->amg_fuse0 != 0;
   prm.fuse_fine_down_only = ctx->amg_fuse0 == 2;
-  auto lap = [&](const char* what) {
-    if (prm.verbose) std::fprintf(stderr, "[amg setup] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-  };
-  lap("operator downloaded");
-  if (!amg::build(std::move(A0), prm, H)) return fail(ctx, HF_ERR_STATE, "AMG set-up failed (non-positive diagonal or singular coarse operator)");
-  lap("+ host hierarchy");
-  const size_t nl = H.levels.size();
-  ctx->amg.resize(nl);
-  for (size_t l = 0; l < nl; ++l) {
+}
+
+// Levels built on the host go to the device: H.levels[k] becomes level base + k of ctx->amg (already sized).
+int upload_host_levels(hf_ctx* ctx, const amg::Hierarchy& H, size_t base) {
+  const bool f32 = ctx->amg_f32;
+  const size_t nl = ctx->amg.size();
+  for (size_t k = 0; k < H.levels.size(); ++k) {
+    const size_t l = base + k;
     DevLevel& L = ctx->amg[l];
-    const amg::Level& hl = H.levels[l];
+    const amg::Level& hl = H.levels[k];
     L.n = static_cast<int>(hl.dinv.size());
     L.omega = hl.omega;
     if (l == 0) {
       if (nl > 1 && hl.Rt.nrow > 0) {            // fused finest level: GP's operand is [r; x_1] = d_r with the level-1 result behind it
         HF_TRY(upload_csr(ctx, hl.Rt, L.Rt, f32));
         if (hl.GP.nrow > 0) HF_TRY(upload_csr(ctx, hl.GP, L.GP, f32));
-        if (L.Rt.rpc == 0 || (hl.GP.nrow > 0 && L.GP.rpc == 0)) {    // too small for the LDS-staged kernel (the only one with the convergence test / r.z epilogue): explicit sweeps
-          free_dev_csr(L.Rt);
-          free_dev_csr(L.GP);
-        }
       }
     } else {
       HF_TRY(upload_csr(ctx, hl.A, L.A));
@@ -174,7 +158,26 @@ int build_amg(hf_ctx* ctx) {
       HF_TRY(upload_csr(ctx, hl.P, L.P, f32));
       // with a fused down leg the single-column cycle applies R_0 itself only after the fine operator has been re-valued
       // under a frozen hierarchy (vcycle); the batched loop always does, through kb_csr, which needs no stream tables
-      HF_TRY(upload_csr(ctx, hl.R, L.R, f32, !(l == 0 && L.Rt.nrow > 0) || ctx->amg_reuse != 0));
+      HF_TRY(upload_csr(ctx, hl.R, L.R, f32, !(l == 0 && hl.Rt.nrow > 0) || ctx->amg_reuse != 0));
+    }
+  }
+  return HF_OK;
+}
+
+// Last steps of a set-up once every level's operators are on the device: the finest level's fused legs are dropped when they
+// are too small for the only kernel that carries their epilogues, the level vectors are wired, the dense inverse of the
+// coarsest operator (host copy Ac) is formed on the device by Gauss-Jordan.
+int finish_amg(hf_ctx* ctx, const amg::Csr& Ac, int coarse_n, double op_complexity, const std::chrono::steady_clock::time_point t0) {
+  const bool f32 = ctx->amg_f32;
+  const size_t nl = ctx->amg.size();
+  auto lap = [&](const char* what) {
+    if (std::getenv("HEATFLOW_DEBUG")) std::fprintf(stderr, "[amg setup] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  };
+  {
+    DevLevel& L = ctx->amg[0];
+    if (L.Rt.nrow > 0 && (L.Rt.rpc == 0 || (L.GP.nrow > 0 && L.GP.rpc == 0))) {    // too small for the LDS-staged kernel (the only one with the convergence test / r.z epilogue): explicit sweeps
+      free_dev_csr(L.Rt);
+      free_dev_csr(L.GP);
     }
   }
   if (std::getenv("HEATFLOW_DEBUG")) {
@@ -189,13 +192,12 @@ int build_amg(hf_ctx* ctx) {
     }
   }
   HF_TRY(wire_levels(ctx));
-  lap("+ operators uploaded");
+  lap("+ operators on the device");
   // coarsest level: dense inverse by Gauss-Jordan on the device
   ctx->coarse_n = 0;
-  if (nl > 1 && H.coarse_n > 0 && H.coarse_n <= 4096) {
-    const int nc = H.coarse_n;
+  if (nl > 1 && coarse_n > 0 && coarse_n <= 4096) {
+    const int nc = coarse_n;
     const int ld = (nc + 3) & ~3;
-    const amg::Csr& Ac = H.levels.back().A;
     std::vector<double> dense(static_cast<size_t>(nc) * nc, 0.0), eye(static_cast<size_t>(nc) * nc, 0.0);
     for (int i = 0; i < nc; ++i) {
       for (int k = Ac.ptr[i]; k < Ac.ptr[i + 1]; ++k) dense[static_cast<size_t>(i) * nc + Ac.idx[k]] = Ac.val[k];
@@ -231,11 +233,36 @@ int build_amg(hf_ctx* ctx) {
     ctx->coarse_n = nc;
   }
   lap("+ dense inverse");
-  ctx->amg_opc = H.op_complexity;
+  ctx->amg_opc = op_complexity;
   ctx->amg_fine_stale = false;
   ctx->amg_ready = true;
   ctx->amg_setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return HF_OK;
+}
+
+// Build the hierarchy from the assembled, eliminated fine operator, everything on the host (download -> host set-up ->
+// upload): the reference implementation of the set-up; hf_amg_gpu.hpp forms the same operators on the device.
+int build_amg(hf_ctx* ctx) {
+  const auto t0 = std::chrono::steady_clock::now();
+  free_amg(ctx);
+  amg::Csr A0;
+  A0.nrow = A0.ncol = ctx->n;
+  A0.ptr.assign(ctx->h_rowptr.begin(), ctx->h_rowptr.end());
+  A0.idx.assign(ctx->h_colidx.begin(), ctx->h_colidx.end());
+  A0.val.resize(ctx->nnz);
+  HF_HIP(copy_sync(ctx, A0.val.data(), ctx->d_A, sizeof(double) * ctx->nnz, hipMemcpyDeviceToHost));
+  amg::Hierarchy H;
+  amg::Params prm;
+  amg_params(ctx, prm);
+  auto lap = [&](const char* what) {
+    if (prm.verbose) std::fprintf(stderr, "[amg setup] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  };
+  lap("operator downloaded");
+  if (!amg::build(std::move(A0), prm, H)) return fail(ctx, HF_ERR_STATE, "AMG set-up failed (non-positive diagonal or singular coarse operator)");
+  lap("+ host hierarchy");
+  ctx->amg.resize(H.levels.size());
+  HF_TRY(upload_host_levels(ctx, H, 0));
+  return finish_amg(ctx, H.levels.back().A, H.coarse_n, H.op_complexity, t0);
 }
 
 // VMODE 0: y = A x, 1: y += A x; LDS-staged kernel when the matrix is big enough to fill the chip,

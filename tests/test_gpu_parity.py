@@ -1216,6 +1216,51 @@ def test_hierarchy_export_and_install_give_a_bit_identical_time_loop(hip):
             e.amg_install(blob)
 
 
+def test_device_built_hierarchy_is_bit_identical_to_the_host_built_one(hip, tmp_path):
+    """The multigrid set-up forms its sparse products, transposes, fused legs and compressed column streams on the device
+    (hf_amg_gpu.hpp) in the order the host routines of amg_host.hpp use; HEATFLOW_AMG_SETUP=host keeps the host-only
+    set-up.  The exported hierarchies (every operator's pointers, indices, values, kernel geometry, column streams, dense
+    inverse) are equal byte for byte, on the stock mesh (two device levels) and on a small one, and so is a time loop."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(os.path.join(ROOT, 'tests'))!r})\n"
+        "from conftest import build_case\n"
+        "from helpers import make_problem\n"
+        "out = {}\n"
+        "for scale in (1.0, 6.0):\n"
+        "    cfg, stack, mesh = build_case('geballe_with_diamond', scale)\n"
+        "    prob = make_problem(cfg, stack, mesh, precond=1, amg_reuse=True)\n"
+        "    out[f'blob{scale}'] = prob.backend.amg_export()\n"
+        "    out[f'rows{scale}'] = np.array(prob.backend.amg_info()['rows'])\n"
+        "    _, _, it = prob.run(10, time_varying=[prob.bcs[3]])\n"
+        "    out[f'u{scale}'] = prob.state(); out[f'it{scale}'] = np.array(it)\n"
+        "    prob.close()\n"
+        "np.savez(sys.argv[1], **out)\n")
+    got = {}
+    for mode in ("device", "host"):
+        env = dict(os.environ)
+        env.pop("HEATFLOW_AMG_SETUP", None)
+        if mode == "host":
+            env["HEATFLOW_AMG_SETUP"] = "host"
+        res = subprocess.run([sys.executable, str(script), str(tmp_path / f"{mode}.npz")], env=env, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        got[mode] = np.load(tmp_path / f"{mode}.npz")
+    for scale in ("1.0", "6.0"):
+        assert np.array_equal(got["device"][f"rows{scale}"], got["host"][f"rows{scale}"])
+        a, b = got["device"][f"blob{scale}"], got["host"][f"blob{scale}"]
+        assert a.shape == b.shape
+        if not np.array_equal(a, b):
+            first = int(np.flatnonzero(a != b)[0])
+            raise AssertionError(f"scale {scale}: hierarchy blobs differ in {int((a != b).sum())} of {a.size} bytes, first at offset {first}")
+        assert np.array_equal(got["device"][f"it{scale}"], got["host"][f"it{scale}"])
+        assert np.array_equal(got["device"][f"u{scale}"], got["host"][f"u{scale}"])
+    assert len(got["device"]["rows1.0"]) >= 4 and got["device"]["rows1.0"][1] > 20000
+
+
 def test_pattern_blob_export_and_prebuilt_install(hip, case_with_diamond_small):
     """hf_pattern_export / hf_set_mesh_prebuilt: the connectivity tables one context built are installed by another
     (host blob, and a blob held in device memory as an RCCL broadcast leaves it); matrices, lazily built scatter
