@@ -1,5 +1,7 @@
 // Part of libheatflow_hip.so (see heatflow_hip.hip): host code - sparsity pattern, owner lists and colouring, launch helpers of the Jacobi-PCG loop
 #pragma once
+#include <thread>
+
 #include "hf_kernels.hpp"
 
 namespace {
@@ -45,32 +47,72 @@ struct Pattern {
   RowGather rg;
 };
 
+// The connectivity tables of hf_set_mesh are built by a few host threads (HEATFLOW_HOST_THREADS, default 16, at most the hardware threads): every table is a
+// loop over independent row blocks whose output sizes are known after a counting pass, so each thread works on a contiguous
+// range of blocks and writes a contiguous slice - no per-thread arrays of mesh size, no concatenation.
+inline int host_threads() {
+  static const int nt = [] {
+    int v = std::getenv("HEATFLOW_HOST_THREADS") ? std::atoi(std::getenv("HEATFLOW_HOST_THREADS")) : 16;
+    const int hw = static_cast<int>(std::thread::hardware_concurrency());
+    if (hw > 0) v = std::min(v, hw);
+    return std::max(1, v);
+  }();
+  return nt;
+}
+
+// f(begin, end, thread index) over [0, n) split into contiguous ranges; small loops stay on the calling thread
+template <typename F>
+void parallel_ranges(int64_t n, int64_t min_per_thread, F&& f) {
+  const int nt = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / std::max<int64_t>(1, min_per_thread))));
+  if (nt <= 1) { f(static_cast<int64_t>(0), n, 0); return; }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { f(n * t / nt, n * (t + 1) / nt, t); });
+  f(static_cast<int64_t>(0), n / nt, 0);
+  for (auto& x : th) x.join();
+}
+
 // false when a chunk touches more than 65535 columns (16-bit positions)
 bool build_coldict(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int32_t n, int rows, ColDict& D,
                    int32_t ncol = -1) {
   if (ncol < 0) ncol = n;
   const int nchunk = (n + rows - 1) / rows;
   D.ptr.assign(static_cast<size_t>(nchunk) + 1, 0);
-  D.dict.clear();
-  D.dict.reserve(static_cast<size_t>(n) + n / 2);
   D.id.resize(colidx.size());
   D.max_dict = 0;
-  std::vector<int32_t> seen(ncol, -1), lid(ncol, 0), list;
-  for (int c = 0; c < nchunk; ++c) {
-    const int64_t k0 = rowptr[static_cast<size_t>(c) * rows], k1 = rowptr[std::min<int64_t>(n, (c + 1LL) * rows)];
-    list.clear();
-    for (int64_t k = k0; k < k1; ++k) {
-      const int32_t col = colidx[k];
-      if (seen[col] != c) { seen[col] = c; list.push_back(col); }
+  // per chunk: the distinct columns (marked in a column-indexed array of the thread's own: one pass, no sorting of the
+  // chunk's thousands of nonzeros), sorted (the chunk's list), and every nonzero's position in it
+  std::vector<std::vector<int32_t>> lists(host_threads());          // each thread's chunks' lists, back to back
+  std::vector<int64_t> first_chunk(host_threads() + 1, 0);
+  std::vector<char> bad(host_threads(), 0);
+  parallel_ranges(nchunk, 64, [&](int64_t c0, int64_t c1, int t) {
+    std::vector<int32_t>& out = lists[t];
+    std::vector<int32_t> seen(ncol, -1), lid(ncol, 0), list;
+    first_chunk[t] = c0;
+    for (int64_t c = c0; c < c1; ++c) {
+      const int64_t k0 = rowptr[static_cast<size_t>(c) * rows], k1 = rowptr[std::min<int64_t>(n, (c + 1) * rows)];
+      list.clear();
+      for (int64_t k = k0; k < k1; ++k) {
+        const int32_t col = colidx[k];
+        if (seen[col] != c) { seen[col] = static_cast<int32_t>(c); list.push_back(col); }
+      }
+      std::sort(list.begin(), list.end());
+      if (list.size() > 65535) { bad[t] = 1; return; }
+      for (size_t q = 0; q < list.size(); ++q) lid[list[q]] = static_cast<int32_t>(q);
+      for (int64_t k = k0; k < k1; ++k) D.id[k] = static_cast<uint16_t>(lid[colidx[k]]);
+      D.ptr[c + 1] = static_cast<int32_t>(list.size());             // lengths now, offsets after the prefix sum below
+      out.insert(out.end(), list.begin(), list.end());
     }
-    std::sort(list.begin(), list.end());
-    if (list.size() > 65535) return false;
-    for (size_t q = 0; q < list.size(); ++q) lid[list[q]] = static_cast<int32_t>(q);
-    for (int64_t k = k0; k < k1; ++k) D.id[k] = static_cast<uint16_t>(lid[colidx[k]]);
-    D.dict.insert(D.dict.end(), list.begin(), list.end());
-    D.ptr[c + 1] = static_cast<int32_t>(D.dict.size());
-    D.max_dict = std::max(D.max_dict, static_cast<int>(list.size()));
+  });
+  for (char b : bad)
+    if (b) return false;
+  for (int c = 0; c < nchunk; ++c) {
+    D.max_dict = std::max(D.max_dict, D.ptr[c + 1]);
+    D.ptr[c + 1] += D.ptr[c];
   }
+  D.dict.resize(static_cast<size_t>(D.ptr[nchunk]));
+  for (size_t t = 0; t < lists.size(); ++t)
+    if (!lists[t].empty()) std::memcpy(D.dict.data() + D.ptr[first_chunk[t]], lists[t].data(), sizeof(int32_t) * lists[t].size());
   return true;
 }
 
@@ -95,16 +137,22 @@ void build_rowgather(int32_t n, int32_t ne, const int32_t* tri, const int32_t* t
   if (G.cols.max_dict > RBA * RG_NX || P.max_blk_nnz + 8 > 8 * RBA * RG_NC) return;
   const int nblk = (n + RBA - 1) / RBA;
   G.hdr.resize(2 * static_cast<size_t>(nblk));
-  G.ell.clear();
-  G.ell.reserve(static_cast<size_t>(8) * n + 8 * RBA);
+  // offsets of the blocks' ELL slabs first (a block's slab is as wide as its busiest node), then the blocks in parallel
+  std::vector<size_t> ell_off(static_cast<size_t>(nblk) + 1, 0);
   for (int b = 0; b < nblk; ++b) {
     const int32_t r0 = b * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
     int w = 0;
     for (int32_t i = r0; i < r1; ++i) w = std::max(w, nptr[i + 1] - nptr[i]);
-    const int groups = std::max(1, (w + 7) / 8);
-    const size_t off = G.ell.size();
-    if (off / 8 > static_cast<size_t>(INT32_MAX)) return;
-    G.ell.resize(off + static_cast<size_t>(groups) * RBA * 8, static_cast<uint16_t>(0xFFFF));
+    ell_off[b + 1] = ell_off[b] + static_cast<size_t>(std::max(1, (w + 7) / 8)) * RBA * 8;
+  }
+  if (ell_off[nblk] / 8 > static_cast<size_t>(INT32_MAX)) return;
+  G.ell.resize(ell_off[nblk]);
+  parallel_ranges(nblk, 64, [&](int64_t b0, int64_t b1, int) {
+  std::fill(G.ell.begin() + ell_off[b0], G.ell.begin() + ell_off[b1], static_cast<uint16_t>(0xFFFF));
+  for (int64_t b = b0; b < b1; ++b) {
+    const int32_t r0 = static_cast<int32_t>(b) * RBA, r1 = std::min<int32_t>(n, r0 + RBA);
+    const size_t off = ell_off[b];
+    const int groups = static_cast<int>((ell_off[b + 1] - off) / (static_cast<size_t>(RBA) * 8));
     const int32_t* dict = &G.cols.dict[G.cols.ptr[b]];
     const int32_t* dend = &G.cols.dict[G.cols.ptr[b + 1]];
     G.hdr[2 * b] = make_int4(P.rowptr[r0], P.rowptr[r1] - P.rowptr[r0], G.cols.ptr[b], G.cols.ptr[b + 1] - G.cols.ptr[b]);
@@ -125,6 +173,7 @@ void build_rowgather(int32_t n, int32_t ne, const int32_t* tri, const int32_t* t
       }
     }
   }
+  });
   G.ok = true;
 }
 
@@ -142,26 +191,45 @@ int build_csr(hf_ctx* ctx, int32_t n, int32_t ne, const int32_t* tri, Pattern& P
       for (int a = 0; a < 3; ++a) nlist[cur[tri[3 * e + a]]++] = e;
   }
   P.rowptr.assign(static_cast<size_t>(n) + 1, 0);
-  P.colidx.clear();
-  P.colidx.reserve(static_cast<size_t>(8) * n);
-  int32_t tmp[3 * 64];
-  std::vector<int32_t> big;
-  for (int32_t i = 0; i < n; ++i) {
-    const int deg = nptr[i + 1] - nptr[i];
-    if (deg == 0) return fail(ctx, HF_ERR_ARG, "node %d belongs to no triangle", i);
-    int32_t* buf = tmp;
-    if (deg > 64) { big.resize(static_cast<size_t>(3) * deg); buf = big.data(); }
-    int m = 0;
-    for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
-      const int32_t e = nlist[q];
-      buf[m++] = tri[3 * e]; buf[m++] = tri[3 * e + 1]; buf[m++] = tri[3 * e + 2];
+  // rows in parallel: every thread sorts the vertex lists of a contiguous range of rows into a buffer of its own (the rows'
+  // lengths go to rowptr), the prefix sum places the buffers one behind the other
+  const int NT = host_threads();
+  std::vector<std::vector<int32_t>> cols(NT);
+  std::vector<int64_t> first_row(NT, 0);
+  std::vector<int32_t> orphan(NT, -1);
+  parallel_ranges(n, 4096, [&](int64_t i0, int64_t i1, int t) {
+    std::vector<int32_t>& out = cols[t];
+    out.reserve(static_cast<size_t>(8) * (i1 - i0));
+    first_row[t] = i0;
+    int32_t tmp[3 * 64];
+    std::vector<int32_t> big;
+    for (int64_t i = i0; i < i1; ++i) {
+      const int deg = nptr[i + 1] - nptr[i];
+      if (deg == 0) { orphan[t] = static_cast<int32_t>(i); return; }
+      int32_t* buf = tmp;
+      if (deg > 64) { big.resize(static_cast<size_t>(3) * deg); buf = big.data(); }
+      int m = 0;
+      for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
+        const int32_t e = nlist[q];
+        buf[m++] = tri[3 * e]; buf[m++] = tri[3 * e + 1]; buf[m++] = tri[3 * e + 2];
+      }
+      std::sort(buf, buf + m);
+      m = static_cast<int>(std::unique(buf, buf + m) - buf);
+      out.insert(out.end(), buf, buf + m);
+      P.rowptr[i + 1] = m;
     }
-    std::sort(buf, buf + m);
-    m = static_cast<int>(std::unique(buf, buf + m) - buf);
-    P.colidx.insert(P.colidx.end(), buf, buf + m);
-    if (P.colidx.size() > static_cast<size_t>(INT32_MAX)) return fail(ctx, HF_ERR_ARG, "nnz exceeds int32");
-    P.rowptr[i + 1] = static_cast<int32_t>(P.colidx.size());
+  });
+  for (int t = 0; t < NT; ++t)
+    if (orphan[t] >= 0) return fail(ctx, HF_ERR_ARG, "node %d belongs to no triangle", orphan[t]);
+  int64_t total = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    total += P.rowptr[i + 1];
+    if (total > static_cast<int64_t>(INT32_MAX)) return fail(ctx, HF_ERR_ARG, "nnz exceeds int32");
+    P.rowptr[i + 1] = static_cast<int32_t>(total);
   }
+  P.colidx.resize(static_cast<size_t>(total));
+  for (int t = 0; t < NT; ++t)
+    if (!cols[t].empty()) std::memcpy(P.colidx.data() + P.rowptr[first_row[t]], cols[t].data(), sizeof(int32_t) * cols[t].size());
   P.max_blk_nnz = 0;
   for (int32_t r0 = 0; r0 < n; r0 += RBA) P.max_blk_nnz = std::max(P.max_blk_nnz, P.rowptr[std::min<int32_t>(n, r0 + RBA)] - P.rowptr[r0]);
   return HF_OK;
