@@ -283,6 +283,20 @@ int parse_mesh_tables(hf_ctx* ctx, const unsigned char* blob, int64_t bytes, int
   return HF_OK;
 }
 
+// A blob handed to hf_set_mesh_prebuilt / hf_amg_install may live in host memory (read in place) or in device memory (what an
+// RCCL broadcast leaves: staged to the host once - its indices are verified there before any kernel follows them)
+int blob_on_host(hf_ctx* ctx, const void* blob, int64_t bytes, std::vector<unsigned char>& staged, const unsigned char** src) {
+  hipPointerAttribute_t at{};
+  const hipError_t e = hipPointerGetAttributes(&at, blob);
+  if (e != hipSuccess) (void)hipGetLastError();            // plain (unregistered) host memory is reported as an error by some runtimes
+  const bool on_device = e == hipSuccess && at.type == hipMemoryTypeDevice;
+  if (!on_device) { *src = static_cast<const unsigned char*>(blob); return HF_OK; }
+  staged.resize(static_cast<size_t>(bytes));
+  HF_HIP(hipMemcpy(staged.data(), blob, static_cast<size_t>(bytes), hipMemcpyDeviceToHost));
+  *src = staged.data();
+  return HF_OK;
+}
+
 // coefficient tables of the row-gather kernel: indexed by position in the mesh's tag dictionary
 int upload_rg_tables(hf_ctx* ctx, const std::vector<double>& by_tag_k, const std::vector<double>* by_tag_c) {
   if (!ctx->rg_ok) return HF_OK;
@@ -484,10 +498,11 @@ int hf_set_mesh_prebuilt(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, c
   if (!ctx) return HF_ERR_ARG;
   if (!zr || !tri || !tag || !blob || n <= 0 || ne <= 0 || bytes <= 0) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: null pointer or empty mesh");
   HF_HIP(hipSetDevice(ctx->dev));
-  std::vector<unsigned char> host(static_cast<size_t>(bytes));     // the blob may live on the host or on a device
-  HF_HIP(hipMemcpy(host.data(), blob, static_cast<size_t>(bytes), hipMemcpyDefault));
+  std::vector<unsigned char> staged;
+  const unsigned char* src = nullptr;
+  HF_TRY(blob_on_host(ctx, blob, bytes, staged, &src));
   MeshTables T;
-  HF_TRY(parse_mesh_tables(ctx, host.data(), bytes, n, ne, T));
+  HF_TRY(parse_mesh_tables(ctx, src, bytes, n, ne, T));
   return install_mesh(ctx, n, ne, zr, tri, tag, T);
 }
 
@@ -697,9 +712,10 @@ int hf_amg_install(hf_ctx* ctx, const void* blob, int64_t bytes) {
   if (ctx->precond != 1 || !ctx->amg_reuse) return fail(ctx, HF_ERR_STATE, "hf_amg_install needs hf_set_precond(1, reuse = 1): an installed hierarchy is a kept one");
   HF_HIP(hipSetDevice(ctx->dev));
   free_batch(ctx);
-  std::vector<unsigned char> host(static_cast<size_t>(bytes));             // the blob may live on the host or on a device
-  HF_HIP(hipMemcpy(host.data(), blob, static_cast<size_t>(bytes), hipMemcpyDefault));
-  HF_TRY(install_hierarchy(ctx, host.data(), host.size()));
+  std::vector<unsigned char> staged;
+  const unsigned char* src = nullptr;
+  HF_TRY(blob_on_host(ctx, blob, bytes, staged, &src));
+  HF_TRY(install_hierarchy(ctx, src, static_cast<size_t>(bytes)));
   ctx->assembled = false;            // the next hf_assemble compares its operator with the hierarchy's fingerprint
   return HF_OK;
 }

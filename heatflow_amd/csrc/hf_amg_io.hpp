@@ -154,7 +154,15 @@ int get_csr(hf_ctx* ctx, BlobIn& in, DevCsr& d, int want_rows /* -1: any */, int
   bool ok = ptr[0] == 0 && ptr[r.nrow] == r.nnz;
   int max_row = 0;
   for (int i = 0; i < r.nrow && ok; ++i) { ok = ptr[i + 1] >= ptr[i]; max_row = std::max(max_row, ptr[i + 1] - ptr[i]); }
-  for (int64_t k = 0; k < r.nnz && ok; ++k) ok = idx[k] >= 0 && idx[k] < r.ncol;
+  if (ok) {                                              // the O(nnz) checks on a few host threads (hf_pattern.hpp)
+    std::vector<char> good(host_threads(), 1);
+    parallel_ranges(r.nnz, 1 << 16, [&](int64_t k0, int64_t k1, int t) {
+      bool g = true;
+      for (int64_t k = k0; k < k1 && g; ++k) g = idx[k] >= 0 && idx[k] < r.ncol;
+      good[t] = g ? 1 : 0;
+    });
+    for (char g : good) ok = ok && g;
+  }
   int chunk_nnz = 0, max_dict = 0;
   if (ok && r.rpc > 0) {
     for (int c = 0; c < r.nchunks; ++c) chunk_nnz = std::max(chunk_nnz, ptr[std::min<int64_t>(r.nrow, (c + 1LL) * r.rpc)] - ptr[static_cast<size_t>(c) * r.rpc]);
@@ -164,10 +172,21 @@ int get_csr(hf_ctx* ctx, BlobIn& in, DevCsr& d, int want_rows /* -1: any */, int
     ok = dptr[0] == 0 && dptr[r.nchunks] == r.ndict;
     for (int c = 0; c < r.nchunks && ok; ++c) {
       const int nd = dptr[c + 1] - dptr[c];
-      ok = nd > 0 && nd <= r.max_dict;
+      ok = nd > 0 && nd <= r.max_dict && dptr[c] >= 0 && dptr[c + 1] <= r.ndict;
       max_dict = std::max(max_dict, nd);
-      for (int32_t k = ptr[static_cast<size_t>(c) * r.rpc]; k < ptr[std::min<int64_t>(r.nrow, (c + 1LL) * r.rpc)] && ok; ++k)
-        ok = cid[k] < nd && dict[dptr[c] + cid[k]] == idx[k];
+    }
+    if (ok) {
+      std::vector<char> good(host_threads(), 1);
+      parallel_ranges(r.nchunks, 64, [&](int64_t c0, int64_t c1, int t) {
+        bool g = true;
+        for (int64_t c = c0; c < c1 && g; ++c) {
+          const int nd = dptr[c + 1] - dptr[c];
+          for (int32_t k = ptr[static_cast<size_t>(c) * r.rpc]; k < ptr[std::min<int64_t>(r.nrow, (c + 1) * r.rpc)] && g; ++k)
+            g = cid[k] < nd && dict[dptr[c] + cid[k]] == idx[k];
+        }
+        good[t] = g ? 1 : 0;
+      });
+      for (char g : good) ok = ok && g;
     }
     for (int64_t k = 0; k < r.ndict && ok; ++k) ok = dict[k] >= 0 && dict[k] < r.ncol;
     ok = ok && static_cast<size_t>(r.chunk_nnz + r.max_dict) * 8 <= 64 * 1024;

@@ -48,7 +48,7 @@ def algorithmic(k):
     if m:
         mode, v, op = int(m.group(1)), int(m.group(2)), int(m.group(3))
         mat = {0: 12, 1: 4 + 8 * v, 2: 20}[op] * nnz + 4 * n
-        per = {9: 40, 4: 32, 3: 24, 0: 16, 5: 32, 2: 40, 8: 32}.get(mode)
+        per = {9: 40, 4: 32, 3: 24, 0: 16, 5: 40, 2: 40, 8: 32}.get(mode)
         return mat + per * n * v if per else None
     m = re.match(r"kb_update<(\d+)", k)
     if m:
