@@ -368,21 +368,23 @@ __global__ __launch_bounds__(KB_BT) void kb_spmv_lds(int n, const int32_t* __res
 // mesh: 30 k rows of 23 entries, 16 -> 11 us): kb_csr below spends NV * log2(lanes) shuffles per row, this kernel
 // log2(EL); for the few long rows of the coarser levels kb_csr's shorter dependent-load chain wins (measured).
 // VMODE 0: y = A x, 1: y += A x.
-template <int NV, int EL, int VMODE, typename VT>
+template <int NV, int CPL /* columns per lane */, int EL /* entry lanes */, int VMODE, typename VT>
 __global__ __launch_bounds__(TPB) void kb_csr_rc(int nrow, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                               const VT* __restrict__ val, const double* __restrict__ x, double* __restrict__ y) {
-  constexpr int TPR = EL * NV;                 // threads per row: a power of two <= 64
-  static_assert(TPR <= 64 && (TPR & (TPR - 1)) == 0, "threads per row");
-  const int j = threadIdx.x % NV, e = (threadIdx.x / NV) % EL;
+  constexpr int NVL = NV / CPL;                // lanes that share an entry, each with CPL adjacent columns
+  constexpr int TPR = EL * NVL;                // threads per row: a power of two <= 64
+  static_assert(NV % CPL == 0 && TPR <= 64 && (TPR & (TPR - 1)) == 0, "threads per row");
+  const int jl = threadIdx.x % NVL, e = (threadIdx.x / NVL) % EL;
   const int rows_per_pass = (gridDim.x * TPB) / TPR;
   for (int row = (blockIdx.x * TPB + threadIdx.x) / TPR; row < nrow; row += rows_per_pass) {
     const int k1 = ptr[row + 1];
-    const size_t o = static_cast<size_t>(row) * NV + j;
-    const double y0 = (VMODE == 1 && e == 0) ? y[o] : 0.0;
-    double s = 0.0;
+    double* yo = y + static_cast<size_t>(row) * NV + jl * CPL;
+    double s[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) s[q] = 0.0;
     for (int k = ptr[row] + e; k < k1; k += 4 * EL) {
       int c[4];
-      double v[4], xv[4];
+      double v[4], xv[4][CPL];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const bool in = k + u * EL < k1;
@@ -390,13 +392,65 @@ __global__ __launch_bounds__(TPB) void kb_csr_rc(int nrow, const int32_t* __rest
         v[u] = in ? static_cast<double>(val[k + u * EL]) : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xv[u] = (k + u * EL < k1) ? x[static_cast<size_t>(c[u]) * NV + j] : 0.0;
+      for (int u = 0; u < 4; ++u) {
+        const double* xs = x + static_cast<size_t>(c[u]) * NV + jl * CPL;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s += v[u] * xv[u];
+        for (int q = 0; q < CPL; ++q) xv[u][q] = (k + u * EL < k1) ? xs[q] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) s[q] += v[u] * xv[u][q];
     }
 #pragma unroll
-    for (int q = EL / 2; q > 0; q >>= 1) s += __shfl_down(s, q * NV, TPR);
-    if (e == 0) y[o] = (VMODE == 1) ? y0 + s : s;
+    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+      for (int o = EL / 2; o > 0; o >>= 1) s[q] += __shfl_down(s[q], o * NVL, TPR);
+    if (e == 0) {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) yo[q] = (VMODE == 1) ? yo[q] + s[q] : s[q];
+    }
+  }
+}
+
+// x = Ainv b with the dense inverse of the coarsest operator in the same mapping: a wavefront per row, lane = (column lane of
+// 64 * CPL / NV, column group of CPL columns).
+template <int NV, int CPL, typename VT>
+__global__ __launch_bounds__(TPB) void kb_dense_rc(int n, int ld, const VT* __restrict__ Ainv, const double* __restrict__ b,
+                                                   double* __restrict__ x) {
+  constexpr int NVL = NV / CPL, CL = 64 / NVL;
+  const int lane = threadIdx.x & 63;
+  const int jl = lane % NVL, cl = lane / NVL;
+  const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * TPB) >> 6;
+  for (int row = wave; row < n; row += nwaves) {
+    const VT* arow = Ainv + static_cast<size_t>(row) * ld;
+    double s[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) s[q] = 0.0;
+    for (int c = cl; c < n; c += 4 * CL) {
+      double a[4], bv[4][CPL];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = c + u * CL < n;
+        a[u] = in ? static_cast<double>(arow[c + u * CL]) : 0.0;
+        const double* bs = b + static_cast<size_t>(in ? c + u * CL : 0) * NV + jl * CPL;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) bv[u][q] = in ? bs[q] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) s[q] += a[u] * bv[u][q];
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+      for (int o = CL / 2; o > 0; o >>= 1) s[q] += __shfl_down(s[q], o * NVL, 64);
+    if (cl == 0) {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) x[static_cast<size_t>(row) * NV + jl * CPL + q] = s[q];
+    }
   }
 }
 
@@ -775,44 +829,61 @@ int ensure_batch_cols(hf_ctx* ctx, int nv) {
 template <int NV, int VMODE, typename VT>
 void blaunch_csr_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y) {
   const double avg = m.nrow ? static_cast<double>(m.nnz) / m.nrow : 1.0;
-  // operators of many rows (>= HEATFLOW_BATCH_RC_ROWS, default 16384) with rows long enough to share: thread = (entry lane, column)
-  static const int rc_rows = std::getenv("HEATFLOW_BATCH_RC_ROWS") ? std::atoi(std::getenv("HEATFLOW_BATCH_RC_ROWS")) : 16384;
-  static const double rc_per_thread = std::getenv("HEATFLOW_BATCH_RC_PER_THREAD") ? std::atof(std::getenv("HEATFLOW_BATCH_RC_PER_THREAD")) : 6.0;
-  static const double rc_min_avg = std::getenv("HEATFLOW_BATCH_RC_MIN_AVG") ? std::atof(std::getenv("HEATFLOW_BATCH_RC_MIN_AVG")) : 20.0;
-  if (m.nrow >= rc_rows && avg >= rc_min_avg) {
-    constexpr int ELMAX = 64 / NV;
-    int el = 1;
-    while (el < ELMAX && avg > rc_per_thread * el) el *= 2;
-    const long long threads = static_cast<long long>(m.nrow) * el * NV;
-    const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 4096)));
-#define HF_BCSR(L) hipLaunchKernelGGL((kb_csr_rc<NV, (L <= ELMAX ? L : ELMAX), VMODE, VT>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, val, x, y)
+  // Mapping lane = (entry lane, group of CPL columns).  CPL = NV is the first kernel of this file (a lane per entry, NV
+  // accumulators, NV * log2(lanes) shuffles per row); CPL < NV trades shuffles for entries per lane.  Defaults from the traces
+  // of the stock hierarchy (profiles/r03_batch_csr_mappings.txt); HEATFLOW_BATCH_CPL / HEATFLOW_BATCH_PER_LANE override.
+  //   8 / 16 columns: four columns per lane, except where rows are few and long (< 1024 rows: the chain of dependent loads
+  //   decides, a lane per entry is shorter) and, for 8 columns, the small operators of middling row length; entries per lane:
+  //   8 (16 columns) or 4 (8 columns) where rows are many (>= 16384: fewer, longer-working lanes), 2.5 where they are few;
+  //   2 / 4 columns: a lane per entry.
+  static const int cpl_env = std::getenv("HEATFLOW_BATCH_CPL") ? std::atoi(std::getenv("HEATFLOW_BATCH_CPL")) : 0;
+  static const double per_lane_env = std::getenv("HEATFLOW_BATCH_PER_LANE") ? std::atof(std::getenv("HEATFLOW_BATCH_PER_LANE")) : 0.0;
+  int cpl = NV;
+  if (NV >= 8 && m.nrow >= 1024 && !(NV == 8 && m.nrow < 4096 && avg < 64.0)) cpl = 4;
+  if (cpl_env > 0) cpl = cpl_env;
+  double per_lane = cpl == NV ? 1.25 : (m.nrow >= 16384 ? (NV >= 16 ? 8.0 : 4.0) : 2.5);
+  if (per_lane_env > 0.0) per_lane = per_lane_env;
+  if (cpl > NV) cpl = NV;
+  while (NV % cpl) --cpl;
+  const int nvl = NV / cpl, elmax = 64 / nvl;
+  int el = cpl == NV ? 2 : 1;
+  while (el < elmax && avg > per_lane * el) el *= 2;
+  const long long threads = static_cast<long long>(m.nrow) * el * nvl;
+  const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 4096)));
+#define HF_RC(C, L) hipLaunchKernelGGL((kb_csr_rc<NV, (C <= NV ? C : NV), ((L) * (NV / (C <= NV ? C : NV)) <= 64 ? (L) : 64 / (NV / (C <= NV ? C : NV))), VMODE, VT>), \
+                                       dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, val, x, y)
+#define HF_RC_EL(C)                                                                      \
+  switch (el) {                                                                          \
+    case 1: HF_RC(C, 1); break;                                                          \
+    case 2: HF_RC(C, 2); break;                                                          \
+    case 4: HF_RC(C, 4); break;                                                          \
+    case 8: HF_RC(C, 8); break;                                                          \
+    case 16: HF_RC(C, 16); break;                                                        \
+    case 32: HF_RC(C, 32); break;                                                        \
+    default: HF_RC(C, 64); break;                                                        \
+  }
+  if (cpl == NV) {
+    // a lane per entry with NV accumulators: the original kernel (its two-entries-per-pass loop suits short dependent chains)
+#define HF_BCSR(L) hipLaunchKernelGGL((kb_csr<NV, L, VMODE, VT>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, val, x, y)
     switch (el) {
-      case 1: HF_BCSR(1); break;
       case 2: HF_BCSR(2); break;
       case 4: HF_BCSR(4); break;
       case 8: HF_BCSR(8); break;
       case 16: HF_BCSR(16); break;
-      default: HF_BCSR(32); break;
+      case 32: HF_BCSR(32); break;
+      default: HF_BCSR(64); break;
     }
 #undef HF_BCSR
     return;
   }
-  // lanes per row: the smallest power of two that leaves a lane about HEATFLOW_BATCH_CSR_PER_LANE (default 1.25) entries
-  static const double per_lane = std::getenv("HEATFLOW_BATCH_CSR_PER_LANE") ? std::atof(std::getenv("HEATFLOW_BATCH_CSR_PER_LANE")) : 1.25;
-  int lanes = 2;
-  while (lanes < 64 && avg > per_lane * lanes) lanes *= 2;
-  const long long threads = static_cast<long long>(m.nrow) * lanes;
-  const int grid = static_cast<int>(std::max(1LL, std::min<long long>((threads + TPB - 1) / TPB, 4096)));
-#define HF_BCSR(L) hipLaunchKernelGGL((kb_csr<NV, L, VMODE, VT>), dim3(grid), dim3(TPB), 0, c->stream, m.nrow, m.ptr, m.idx, val, x, y)
-  switch (lanes) {
-    case 2: HF_BCSR(2); break;
-    case 4: HF_BCSR(4); break;
-    case 8: HF_BCSR(8); break;
-    case 16: HF_BCSR(16); break;
-    case 32: HF_BCSR(32); break;
-    default: HF_BCSR(64); break;
+  switch (cpl) {
+    case 1: HF_RC_EL(1); break;
+    case 2: HF_RC_EL(2); break;
+    case 4: HF_RC_EL(4); break;
+    default: HF_RC_EL(8); break;
   }
-#undef HF_BCSR
+#undef HF_RC_EL
+#undef HF_RC
 }
 
 template <int NV, int VMODE>
@@ -908,7 +979,12 @@ struct BatchOps {
       const DevLevel& Lc = c->amg[nl - 1];
       if (c->coarse_n > 0) {
         const int g = std::max(1, std::min((Lc.n + 3) / 4, 1024));
-        if (c->d_coarse_inv_f != nullptr)
+        static const int dense_cpl = std::getenv("HEATFLOW_BATCH_DENSE_CPL") ? std::atoi(std::getenv("HEATFLOW_BATCH_DENSE_CPL")) : NV;   // measured: a lane per column wins (few rows)
+        constexpr int DC = NV >= 4 ? 4 : NV;
+        if (dense_cpl < NV && c->d_coarse_inv_f != nullptr)
+          hipLaunchKernelGGL((kb_dense_rc<NV, DC, float>), dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv_f,
+                             B.lev[nl - 1].b, B.lev[nl - 1].res);
+        else if (c->d_coarse_inv_f != nullptr)
           hipLaunchKernelGGL((kb_dense<NV, float>), dim3(g), dim3(TPB), 0, c->stream, Lc.n, c->coarse_ld, c->d_coarse_inv_f,
                              B.lev[nl - 1].b, B.lev[nl - 1].res);
         else
