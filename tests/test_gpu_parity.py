@@ -1261,6 +1261,45 @@ def test_device_built_hierarchy_is_bit_identical_to_the_host_built_one(hip, tmp_
     assert len(got["device"]["rows1.0"]) >= 4 and got["device"]["rows1.0"][1] > 20000
 
 
+def test_sweep_blobs_in_torch_device_memory_are_installed_by_address(hip, tmp_path):
+    """What a non-zero rank of an RCCL sweep does after the broadcasts: connectivity tables and multigrid hierarchy sit in torch
+    tensors on the device (parameter_sweep.DeviceBlob) and the solver session installs both by address - no host copy on the
+    Python side.  torch is imported before the library is loaded (one HIP runtime for both), hence the subprocess.  The run
+    equals the one of a session that built everything itself, bit for bit."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        "import torch\n"
+        f"sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(os.path.join(ROOT, 'tests'))!r})\n"
+        "from conftest import build_case, HEATING_CSV\n"
+        "from heatflow_amd.driver import SimulationSession\n"
+        "from heatflow_amd.geometry import watcher_points\n"
+        "from heatflow_amd.parameter_sweep import DeviceBlob\n"
+        "cfg, stack, mesh = build_case('geballe_with_diamond', 4.0)\n"
+        "cfg['heating']['file'] = HEATING_CSV\n"
+        "cfg['timing']['num_steps'] = 12; cfg['timing']['t_final'] = 12 * 7.5e-8\n"
+        "a = SimulationSession(mesh.coords, mesh.tris, mesh.tags, mesh.material_tags)\n"
+        "ra = a.run(cfg, stack, watcher_points(cfg))\n"
+        "pat = a.problem.backend.export_pattern(); share = a.export_hierarchy()\n"
+        "dev = torch.device('cuda', 0)\n"
+        "tp = torch.from_numpy(pat).to(dev); th = torch.from_numpy(share['blob']).to(dev); torch.cuda.synchronize()\n"
+        "b = SimulationSession(mesh.coords, mesh.tris, mesh.tags, mesh.material_tags, pattern=DeviceBlob(tp),\n"
+        "                      hierarchy={'blob': DeviceBlob(th), 'k': share['k']})\n"
+        "rb = b.run(cfg, stack, watcher_points(cfg))\n"
+        "info = (a.problem.backend.amg_info(), b.problem.backend.amg_info())\n"
+        "ua, ub = a.problem.state(), b.problem.state()\n"
+        "a.close(); b.close()\n"
+        "assert info[0]['rows'] == info[1]['rows'], info\n"
+        "assert np.array_equal(ra['iters'], rb['iters']) and np.array_equal(ua, ub), (ra['iters'], rb['iters'])\n"
+        "assert np.array_equal(ra['watchers']['oside'], rb['watchers']['oside']) and ra['iters'].max() >= 4\n"
+        "print('ok', len(DeviceBlob(tp)), len(DeviceBlob(th)))\n")
+    res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert res.returncode == 0 and res.stdout.strip().splitlines()[-1].startswith("ok"), res.stderr[-3000:]
+
+
 def test_pattern_blob_export_and_prebuilt_install(hip, case_with_diamond_small):
     """hf_pattern_export / hf_set_mesh_prebuilt: the connectivity tables one context built are installed by another
     (host blob, and a blob held in device memory as an RCCL broadcast leaves it); matrices, lazily built scatter
