@@ -352,6 +352,8 @@ class Ranks:
         self.dist, self.torch = None, None
         self.backend, self.dev_index = "nccl", self.local_rank
         if self.world > 1 or os.environ.get("HEATFLOW_BENCH_FORCE_DIST") == "1":   # the latter: rehearse the RCCL path on 1 GPU
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)   # a forced world of one started without a launcher
             import torch                      # torch first: its bundled HIP runtime must be the one both sides use
             import torch.distributed as dist
             # HEATFLOW_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks

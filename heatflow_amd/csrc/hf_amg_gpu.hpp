@@ -397,7 +397,7 @@ int adopt_csr(hf_ctx* ctx, GpuScratch& S, GCsr& g, DevCsr& d, bool f32, bool str
   d = DevCsr();
   d.nrow = g.nrow; d.ncol = g.ncol; d.nnz = g.nnz;
   const double avg = g.nrow ? static_cast<double>(g.nnz) / g.nrow : 1.0;
-  d.lanes = avg <= 4.5 ? 4 : avg <= 9.0 ? 8 : avg <= 18.0 ? 16 : avg <= 36.0 ? 32 : avg <= 128.0 ? 64 : 256;       // lanes_for()
+  d.lanes = lanes_for_avg(avg);
   std::vector<int32_t> hptr(static_cast<size_t>(g.nrow) + 1);
   HF_HIP(copy_sync(ctx, hptr.data(), g.ptr, sizeof(int32_t) * hptr.size(), hipMemcpyDeviceToHost));
   for (int i = 0; i < g.nrow; ++i) d.max_row = std::max(d.max_row, hptr[i + 1] - hptr[i]);

@@ -26,10 +26,13 @@ void free_amg(hf_ctx* ctx) {
   ctx->amg_ready = false;
 }
 
-int lanes_for(const amg::Csr& m) {
-  const double avg = m.nrow ? static_cast<double>(m.nnz()) / m.nrow : 1.0;
-  return avg <= 4.5 ? 4 : avg <= 9.0 ? 8 : avg <= 18.0 ? 16 : avg <= 36.0 ? 32 : avg <= 128.0 ? 64 : 256;
+// lanes of a wavefront that share a row in the sub-wave kernels: about one entry per lane (HEATFLOW_VEC_PER_LANE: A/B)
+int lanes_for_avg(double avg) {
+  static const double scale = std::getenv("HEATFLOW_VEC_PER_LANE") ? std::atof(std::getenv("HEATFLOW_VEC_PER_LANE")) / 1.125 : 1.0;
+  const double a = avg / scale;
+  return a <= 4.5 ? 4 : a <= 9.0 ? 8 : a <= 18.0 ? 16 : a <= 36.0 ? 32 : (a <= 128.0 || scale != 1.0) ? 64 : 256;
 }
+int lanes_for(const amg::Csr& m) { return lanes_for_avg(m.nrow ? static_cast<double>(m.nnz()) / m.nrow : 1.0); }
 
 // f32: values stored in single precision (operators that only act inside the preconditioner).  Operators big enough
 // for the LDS-staged kernel also get its compressed column stream (a sorted column list per chunk + a 16-bit position
