@@ -364,13 +364,16 @@ class Ranks:
                 raise SystemExit(f"bench.py: {self.world} ranks but {ndev} GPU(s) visible: RCCL needs one GPU per rank "
                                  "(HEATFLOW_BENCH_BACKEND=gloo rehearses the code path on fewer GPUs)")
             self.dev_index = self.local_rank % max(ndev, 1)
+            # a collective that never completes (a rank that died or raised between two of them) must end the run, not hang it
+            import datetime
+            limit = datetime.timedelta(seconds=int(os.environ.get("HEATFLOW_BENCH_DIST_TIMEOUT_S", "240")))
             if self.backend == "nccl":
                 torch.cuda.set_device(self.dev_index)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index), timeout=limit)
             else:
                 if ndev > 0:
                     torch.cuda.set_device(self.dev_index)
-                dist.init_process_group(self.backend)
+                dist.init_process_group(self.backend, timeout=limit)
             self.dist, self.torch = dist, torch
             self.world, self.rank = dist.get_world_size(), dist.get_rank()
 
@@ -712,9 +715,17 @@ def main(argv=None):
     prob.close()
 
     # ---- side measurements: the C5 sweep (every N), the HBM-resident roofline point (N = 1)
-    sweep = run_sweep64(ranks, args.sweep_points, 100, max(1, args.warmup), args.sweep_concurrent, args.sweep_batch) if args.sweep_points > 0 else None
+    # (the headline's timing and every collective it needs are done: a failure of a side measurement is reported in its place,
+    # it does not take the line with it)
+    sweep = None
+    if args.sweep_points > 0:
+        try:
+            sweep = run_sweep64(ranks, args.sweep_points, 100, max(1, args.warmup), args.sweep_concurrent, args.sweep_batch)
+        except BaseException as e:          # noqa: BLE001 - SystemExit of a failed point included
+            sys.stderr.write(f"bench.py: the C5 side measurement failed on rank {rank}: {type(e).__name__}: {e}\n")
+            sweep = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
     hbm = hbm_resident_point(args.hbm_scale, dev_index, 3) if (world == 1 and args.hbm_scale > 0) else None
-    batch_roof = batch_head_roofline(dev_index, args.sweep_batch) if (world == 1 and sweep is not None and args.batch_roofline and args.sweep_batch > 1) else None
+    batch_roof = batch_head_roofline(dev_index, args.sweep_batch) if (world == 1 and sweep is not None and "error" not in sweep and args.batch_roofline and args.sweep_batch > 1) else None
 
     if rank == 0:
         out = dict(common, metric="DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond",
@@ -760,7 +771,9 @@ def main(argv=None):
             out["config"]["amg"] = dict(amg_info, precision=PRECISION_TEXT)
         if jacobi is not None:
             out["config"]["jacobi_pcg"] = jacobi
-        if sweep is not None:
+        if sweep is not None and "error" in sweep:
+            out["config"]["sweep64"] = sweep
+        elif sweep is not None:
             if farm:
                 sweep["cpu_farm_baseline"] = farm
             attach_farms(sweep, sweep["value"], farm, farm8)
@@ -775,7 +788,10 @@ def main(argv=None):
         else:
             out["cpu_baseline"] = None
         emit(out)
-    ranks.close()
+    try:
+        ranks.close()
+    except Exception as e:                  # noqa: BLE001 - the line is out; a process group broken by a failed side measurement must not change the exit code
+        sys.stderr.write(f"bench.py: closing the process group failed: {e}\n")
     return 0
 
 
