@@ -1,10 +1,13 @@
 /* libheatflow_host.so - host-only helpers of the mesh layer (see include/heatflow_host.h). */
+#define _POSIX_C_SOURCE 200809L
 #include "heatflow_host.h"
 
 #include <errno.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 int hfh_version(void) { return 1; }
 
@@ -68,6 +71,41 @@ int hfh_write_msh22(const char* path, int32_t n, int32_t ne, const double* coord
 
 typedef struct { int8_t* p; int32_t nz, nr; } grid8;
 
+/* The dense passes over the base grid (1e8 cells for a 1M-node mesh) are row-parallel: body(r0, r1, arg) on row ranges,
+ * on up to HEATFLOW_HOST_THREADS (default 16) threads when the grid is big enough to pay for starting them. */
+typedef void (*row_body)(int32_t r0, int32_t r1, void* arg);
+typedef struct { row_body f; void* arg; int32_t r0, r1; } row_job;
+static void* row_thread(void* p) { row_job* j = (row_job*)p; j->f(j->r0, j->r1, j->arg); return NULL; }
+static int host_threads(void) {
+  static int nt = 0;
+  if (nt == 0) {
+    const char* e = getenv("HEATFLOW_HOST_THREADS");
+    int v = e ? atoi(e) : 16;
+    const long hw = sysconf(_SC_NPROCESSORS_ONLN);
+    if (hw > 0 && v > hw) v = (int)hw;
+    nt = v < 1 ? 1 : (v > 64 ? 64 : v);
+  }
+  return nt;
+}
+static void par_rows(int32_t nrows, size_t cells, row_body f, void* arg) {
+  int nt = host_threads();
+  if (cells < ((size_t)1 << 21) || nrows < 2 * nt) nt = 1;
+  if (nt == 1) { f(0, nrows, arg); return; }
+  pthread_t th[64];
+  row_job job[64];
+  int started = 0;
+  for (int t = 1; t < nt; ++t) {
+    job[t].f = f; job[t].arg = arg;
+    job[t].r0 = (int32_t)((int64_t)nrows * t / nt); job[t].r1 = (int32_t)((int64_t)nrows * (t + 1) / nt);
+    if (pthread_create(&th[t], NULL, row_thread, &job[t]) != 0) { f(job[t].r0, job[t].r1, arg); th[t] = 0; job[t].f = NULL; }
+    else ++started;
+  }
+  f(0, (int32_t)((int64_t)nrows / nt), arg);
+  for (int t = 1; t < nt; ++t)
+    if (job[t].f) pthread_join(th[t], NULL);
+  (void)started;
+}
+
 static int grid_alloc(grid8* g, int32_t nz, int32_t nr) {
   g->nz = nz; g->nr = nr;
   g->p = (int8_t*)malloc((size_t)nz * (size_t)nr > 0 ? (size_t)nz * (size_t)nr : 1);
@@ -78,17 +116,45 @@ static inline int8_t min4(int8_t a, int8_t b, int8_t c, int8_t d) { int8_t m = a
 static inline int8_t max4(int8_t a, int8_t b, int8_t c, int8_t d) { int8_t m = a > b ? a : b; int8_t n = c > d ? c : d; return m > n ? m : n; }
 
 /* 2x2 block minimum / maximum of src into dst (dst is half the size) */
-static void reduce_min(const grid8* s, grid8* d) {
-  for (int32_t i = 0; i < d->nz; ++i) {
+typedef struct { const grid8* s; grid8* d; } reduce_arg;
+static void reduce_min_rows(int32_t i0, int32_t i1, void* p) {
+  const grid8* s = ((reduce_arg*)p)->s; grid8* d = ((reduce_arg*)p)->d;
+  for (int32_t i = i0; i < i1; ++i) {
     const int8_t* r0 = s->p + (size_t)(2 * i) * s->nr; const int8_t* r1 = r0 + s->nr; int8_t* o = d->p + (size_t)i * d->nr;
     for (int32_t j = 0; j < d->nr; ++j) o[j] = min4(r0[2 * j], r0[2 * j + 1], r1[2 * j], r1[2 * j + 1]);
   }
 }
-static void reduce_max(const grid8* s, grid8* d) {
-  for (int32_t i = 0; i < d->nz; ++i) {
+static void reduce_max_rows(int32_t i0, int32_t i1, void* p) {
+  const grid8* s = ((reduce_arg*)p)->s; grid8* d = ((reduce_arg*)p)->d;
+  for (int32_t i = i0; i < i1; ++i) {
     const int8_t* r0 = s->p + (size_t)(2 * i) * s->nr; const int8_t* r1 = r0 + s->nr; int8_t* o = d->p + (size_t)i * d->nr;
     for (int32_t j = 0; j < d->nr; ++j) o[j] = max4(r0[2 * j], r0[2 * j + 1], r1[2 * j], r1[2 * j + 1]);
   }
+}
+static void reduce_min(const grid8* s, grid8* d) { reduce_arg a = {s, d}; par_rows(d->nz, (size_t)s->nz * s->nr, reduce_min_rows, &a); }
+static void reduce_max(const grid8* s, grid8* d) { reduce_arg a = {s, d}; par_rows(d->nz, (size_t)s->nz * s->nr, reduce_max_rows, &a); }
+
+typedef struct { const grid8 *cur, *ok; grid8* nxt; int lv; const int8_t* mat; int8_t* level; int32_t nrp; } topdown_arg;
+static void topdown_rows(int32_t i0, int32_t i1, void* p) {            /* a cell's level = the highest admissible block above it */
+  const topdown_arg* a = (const topdown_arg*)p;
+  for (int32_t i = i0; i < i1; ++i)
+    for (int32_t j = 0; j < a->nxt->nr; ++j) {
+      const int8_t par = a->cur->p ? a->cur->p[(size_t)(i >> 1) * a->cur->nr + (j >> 1)] : (int8_t)-1;
+      a->nxt->p[(size_t)i * a->nxt->nr + j] = par >= 0 ? par : (a->ok->p[(size_t)i * a->nxt->nr + j] ? (int8_t)a->lv : (int8_t)-1);
+    }
+}
+static void level0_rows(int32_t i0, int32_t i1, void* p) {
+  const topdown_arg* a = (const topdown_arg*)p;
+  for (int32_t i = i0; i < i1; ++i)
+    for (int32_t j = 0; j < a->nrp; ++j) {
+      const int8_t par = a->cur->p ? a->cur->p[(size_t)(i >> 1) * a->cur->nr + (j >> 1)] : (int8_t)-1;
+      a->level[(size_t)i * a->nrp + j] = par >= 0 ? par : (a->mat[(size_t)i * a->nrp + j] >= 0 ? (int8_t)0 : (int8_t)-1);
+    }
+}
+typedef struct { const int8_t* level; int8_t* out; int32_t nrp; } pyr0_arg;
+static void pyr0_rows(int32_t i0, int32_t i1, void* p) {
+  const pyr0_arg* a = (const pyr0_arg*)p;
+  for (size_t q = (size_t)i0 * a->nrp; q < (size_t)i1 * a->nrp; ++q) a->out[q] = a->level[q] < 0 ? 127 : a->level[q];
 }
 
 int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* mat, const int8_t* allowed, int8_t* level) {
@@ -128,20 +194,15 @@ int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* ma
     for (int lv = top; lv >= 1 && rc == 0; --lv) {     /* cur: assigned level (or -1) on the grid of level lv */
       grid8 nxt;
       if (grid_alloc(&nxt, nzp >> lv, nrp >> lv)) { rc = -ENOMEM; break; }
-      for (int32_t i = 0; i < nxt.nz; ++i)
-        for (int32_t j = 0; j < nxt.nr; ++j) {
-          const int8_t par = cur.p ? cur.p[(size_t)(i >> 1) * cur.nr + (j >> 1)] : (int8_t)-1;
-          nxt.p[(size_t)i * nxt.nr + j] = par >= 0 ? par : (ok[lv].p[(size_t)i * nxt.nr + j] ? (int8_t)lv : (int8_t)-1);
-        }
+      topdown_arg ta = {&cur, &ok[lv], &nxt, lv, mat, level, nrp};
+      par_rows(nxt.nz, (size_t)nxt.nz * nxt.nr, topdown_rows, &ta);
       free(cur.p);
       cur = nxt;
     }
-    if (rc == 0)
-      for (int32_t i = 0; i < nzp; ++i)
-        for (int32_t j = 0; j < nrp; ++j) {
-          const int8_t par = cur.p ? cur.p[(size_t)(i >> 1) * cur.nr + (j >> 1)] : (int8_t)-1;
-          level[(size_t)i * nrp + j] = par >= 0 ? par : (mat[(size_t)i * nrp + j] >= 0 ? (int8_t)0 : (int8_t)-1);
-        }
+    if (rc == 0) {
+      topdown_arg ta = {&cur, NULL, NULL, 0, mat, level, nrp};
+      par_rows(nzp, N, level0_rows, &ta);
+    }
     free(cur.p);
   }
   for (int lv = 0; lv <= lmax; ++lv) free(ok[lv].p);
@@ -158,7 +219,8 @@ int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* ma
   /* the min-pyramid is built once and kept consistent: a demotion rewrites its block on every finer level, the
    * coarser levels are re-reduced on the way up (levels 0 and 1 never change a decision, so a sweep costs N/4) */
   if (rc == 0) {
-    for (size_t q = 0; q < N; ++q) pyr[0].p[q] = level[q] < 0 ? BIG : level[q];
+    pyr0_arg pa0 = {level, pyr[0].p, nrp};
+    par_rows(nzp, N, pyr0_rows, &pa0);
     if (lmax >= 1) reduce_min(&pyr[0], &pyr[1]);
   }
   int converged = 0;
