@@ -27,6 +27,10 @@ refined to ~1M DOF (BASELINE.json configs[2] / BASELINE.md C3).
   / its average duration INSIDE the loop (kernel-attached HIP events on the solver's stream on the launches
   of extra steps right after the timed region; agrees with rocprofv3's in-loop figure, profiles/).  The
   back-to-back figure (100 launches) and the bytes the compressed column format really moves are beside it.
+  ``roofline.traffic`` = HBM bytes per launch of that kernel from the PMC counters, measured in the same invocation: two
+  child runs of this script (``--pmc-child``) under ``rocprofv3 --pmc FETCH_SIZE`` and ``--pmc WRITE_SIZE`` (separate passes,
+  counters only), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; ``roofline.traffic_source`` says so, or names the kept file it fell
+  back to (``--traffic file``) when the profiler is not available.
   At 1M DOF the iteration's working set sits in the 256 MiB Infinity Cache; ``roofline.hbm_resident`` repeats
   the measurement on a mesh whose matrix is far beyond it (``--hbm-scale``, 16M DOF).  ``roofline.assembly``
   holds the element kernel's variants.
@@ -95,6 +99,11 @@ def parse_args(argv=None):
                          "parameter_sweep.py:389-390, 423-446); 0 = skip.  Runs before anything touches the GPU")
     ap.add_argument("--cpu-farm-procs", type=int, default=0, help="processes of that pool (0 = min(points, usable cores))")
     ap.add_argument("--batch-roofline", type=int, default=1, help="N = 1: roofline of the batched iteration head (0 = skip)")
+    ap.add_argument("--traffic", choices=["live", "file", "none"], default="live",
+                    help="roofline.traffic (HBM bytes of the dominant kernel per launch, PMC): live = measured now by two child runs of this "
+                         "script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (N = 1; +15-20 s), falling back to the figures kept "
+                         "under profiles/ when the profiler is not available; file = those figures only")
+    ap.add_argument("--pmc-child", choices=["c3", "batch"], default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-farm-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="form the process group, report its size and exit: checks the launcher plumbing (no GPU work)")
@@ -270,7 +279,7 @@ def attach_farms(cfg_out, gpu_value, farm, farm8):
             cfg_out["gpu_over_cpu_farm_8_points"] = gpu_value / farm8["value"]
 
 
-def batch_head_roofline(dev_index, nv, profile_steps=8):
+def batch_head_roofline(dev_index, nv, profile_steps=8, traffic_mode="file"):
     """Roofline of the batched loop's dominant kernel, the iteration head kb_spmv_lds<9, nv, affine> (the C5 sweep: nv
     kappa_sample points as the columns of one multi-vector PCG).  In-loop: kernel-attached HIP events on its launches
     inside the time loop of one batch (hf_set_profile), on the stock mesh (the C5 size; the batch's working set of
@@ -324,22 +333,109 @@ def batch_head_roofline(dev_index, nv, profile_steps=8):
 
     stock = one(1.0, 30)
     big = one(MESH_SCALE, 10)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic_batch_latest.json")) as f:
-            pmc = json.load(f)
-        if pmc["n"] == stock["n_dof"] and pmc["nnz"] == stock["nnz"] and pmc["nv"] == nv:
-            traffic = pmc["kernels"][f"kb_spmv_lds<9,nv{nv},op2>"]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, traffic_note = None, "not measured"
+    if traffic_mode == "live":
+        traffic, traffic_note = live_traffic("batch", rf"kb_spmv_lds<9, {nv}, 2>", ["--sweep-batch", str(nv)])
+        if traffic is None:
+            traffic_note = f"live measurement not available ({traffic_note}); "
+    if traffic is None and traffic_mode != "none":
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_batch_latest.json")) as f:
+                pmc = json.load(f)
+            if pmc["n"] == stock["n_dof"] and pmc["nnz"] == stock["nnz"] and pmc["nv"] == nv:
+                traffic = pmc["kernels"][f"kb_spmv_lds<9,nv{nv},op2>"]["hbm_bytes"]
+                traffic_note = (traffic_note if traffic_note.startswith("live") else "") + \
+                    "figure kept under profiles/pmc_traffic_batch_latest.json (same matrix and nv; scripts/profile_batch.sh)"
+        except (OSError, KeyError, ValueError):
+            pass
     return {"bound": "hbm", "achieved": stock["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stock["frac"], "traffic": traffic,
             "kernel": f"kb_spmv_lds<9, {nv}, affine> (batched PCG iteration head: CSR SpMV on {nv} interleaved columns with the direction update fused; "
                       "chunk operands staged in LDS, 16-bit column positions)",
             "bytes_per_launch": stock["bytes_per_launch"], "us_per_launch": stock["us_per_launch_in_loop_events"],
             "formula": "(4 + 16)*nnz + 4*n + 40*n*nv",
             "timing": "in-loop: kernel-attached HIP events on the kb_spmv_lds<9> launches of one batch's time loop",
-            "traffic_note": "PMC (2*FETCH_SIZE + WRITE_SIZE)*1024 of profiles/pmc_traffic_batch_latest.json when collected on this matrix and nv",
+            "traffic_source": traffic_note,
             "stock_size": stock, "hbm_resident": big}
+
+
+def pmc_child(args):
+    """Body of `bench.py --pmc-child c3|batch`, run under `rocprofv3 --pmc <counter>`: a few steps of the measured loop, nothing else."""
+    if args.pmc_child == "c3":
+        cfg, stack, mesh = build_problem_inputs(args.scale)
+        prob = make_problem(cfg, stack, mesh.coords, mesh.tris, mesh.tags, mesh.material_tags, None, 0, 1)
+        for bc in prob.bcs:
+            bc.update(0.0)
+        prob.run(9, time_varying=[prob.bcs[3]], first_step=0)          # steps 0-4 carry no heating, 5-8 iterate
+        print(json.dumps({"n": prob.backend.n, "nnz": prob.backend.nnz}))
+        prob.close()
+    else:
+        import copy
+        import yaml
+        from heatflow_amd import parameter_sweep as ps
+        from heatflow_amd.driver import SimulationSession, suppress_output
+        from heatflow_amd.geometry import build_stack, watcher_points
+        from heatflow_amd.mesh import Mesh
+        with open(os.path.join(ROOT, "cfgs", "geballe_with_diamond.yaml")) as f:
+            cfg = yaml.safe_load(f)
+        cfg["heating"]["file"] = os.path.join(ROOT, cfg["heating"]["file"])
+        dt0 = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
+        cfg["timing"]["num_steps"], cfg["timing"]["t_final"] = 12, dt0 * 12
+        stack = build_stack(cfg)
+        mesh = Mesh("mesh.msh", stack.bounds, stack.materials).build_mesh()
+        sess = SimulationSession(mesh.coords, mesh.tris, mesh.tags, mesh.material_tags)
+        cfgs = []
+        for k in ps.get_k_values(count=64)[:args.sweep_batch]:
+            c = copy.deepcopy(cfg)
+            c["mats"]["p_sample"]["k"] = float(k)
+            cfgs.append(c)
+        with suppress_output(True):
+            sess.run_batch(cfgs, [build_stack(c) for c in cfgs], watcher_points(cfgs[0]))
+        print(json.dumps({"n": sess.problem.backend.n, "nnz": sess.problem.backend.nnz}))
+        sess.close()
+    return 0
+
+
+def live_traffic(kind, kernel_regex, extra_args=()):
+    """HBM bytes per launch of one kernel, measured now: this script is run twice as a child under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md, HBM section); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024
+    (gfx950 counts 64 B per 128-B request in FETCH_SIZE), each counter's 90th percentile over the launches (launches that return at
+    their first instruction after convergence read nothing).  Returns (bytes, note) or (None, why not)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="hf_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", out, "-o", "run", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", kind] + list(extra_args)
+            try:
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} timed out"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (exit {p.returncode})"
+            v = []
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if re.search(kernel_regex, r["Kernel_Name"]):
+                        v.append(float(r["Counter_Value"]))
+            if not v:
+                return None, f"no launch of {kernel_regex} in the {counter} pass"
+            v.sort()
+            vals[counter] = v[max(0, int(0.9 * len(v)) - 1)]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
+        "measured in this run: child runs of bench.py under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, (2*FETCH_SIZE + WRITE_SIZE)*1024, p90 over the launches"
 
 
 class Ranks:
@@ -582,6 +678,8 @@ def main(argv=None):
     args = parse_args(argv)
     if args.cpu_farm_worker:
         return cpu_farm_worker(args.cpu_farm_points, args.steps or 100, args.cpu_farm_procs)
+    if args.pmc_child:
+        return pmc_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args, argv)
     # C5's CPU baseline is a pool of processes: it runs to completion here, before this process touches the GPU
@@ -624,7 +722,7 @@ def main(argv=None):
     if args.workload == "sweep64":
         sw = run_sweep64(ranks, SWEEP_POINTS, args.steps, args.warmup, args.sweep_concurrent, args.sweep_batch)
         if rank == 0:
-            roof = batch_head_roofline(dev_index, args.sweep_batch) if (world == 1 and args.batch_roofline and args.sweep_batch > 1) else None
+            roof = batch_head_roofline(dev_index, args.sweep_batch, traffic_mode=args.traffic) if (world == 1 and args.batch_roofline and args.sweep_batch > 1) else None
             out = dict(common, metric="DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond", value=sw["value"],
                        ms_per_step=1e3 * sw["wall_s"] / args.steps, scaling="strong",
                        config={"workload": sw["workload"], "solver": SOLVER_TEXT, "precision": PRECISION_TEXT,
@@ -685,14 +783,21 @@ def main(argv=None):
     stream_gbs = 12 * nnz / (k_us["stream_read"] * 1e-6) / 1e9
     # HBM traffic of that kernel from the PMC passes kept under profiles/ (rocprofv3 cannot wrap itself):
     # only quoted when it was collected on exactly this matrix
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
-            pmc = json.load(f)
-        if pmc["n"] == n and pmc["nnz"] == nnz:
-            traffic = pmc["kernels"]["k_spmv<9>"]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, traffic_note = None, "not measured"
+    if args.traffic == "live" and world == 1:
+        traffic, traffic_note = live_traffic("c3", r"k_spmv<9, ", ["--scale", str(args.scale)])
+        if traffic is None:
+            traffic_note = f"live measurement not available ({traffic_note}); "
+    if traffic is None and args.traffic != "none":
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
+                pmc = json.load(f)
+            if pmc["n"] == n and pmc["nnz"] == nnz:
+                traffic = pmc["kernels"]["k_spmv<9>"]["hbm_bytes"]
+                traffic_note = (traffic_note if traffic_note.startswith("live") else "") + \
+                    "figure kept under profiles/pmc_traffic_latest.json (same matrix; rocprofv3 --pmc passes of scripts/profile_round.sh)"
+        except (OSError, KeyError, ValueError):
+            pass
     moved = traffic if traffic else 10 * nnz + 44 * n
     amg_info = be.amg_info() if precond == 1 else None
     asm_roof = None
@@ -725,7 +830,7 @@ def main(argv=None):
             sys.stderr.write(f"bench.py: the C5 side measurement failed on rank {rank}: {type(e).__name__}: {e}\n")
             sweep = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
     hbm = hbm_resident_point(args.hbm_scale, dev_index, 3) if (world == 1 and args.hbm_scale > 0) else None
-    batch_roof = batch_head_roofline(dev_index, args.sweep_batch) if (world == 1 and sweep is not None and "error" not in sweep and args.batch_roofline and args.sweep_batch > 1) else None
+    batch_roof = batch_head_roofline(dev_index, args.sweep_batch, traffic_mode="file" if args.traffic == "live" else args.traffic) if (world == 1 and sweep is not None and "error" not in sweep and args.batch_roofline and args.sweep_batch > 1) else None
 
     if rank == 0:
         out = dict(common, metric="DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond",
@@ -753,6 +858,7 @@ def main(argv=None):
             "bytes_moved_per_launch": moved,
             "frac_bytes_moved": moved / (spmv_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "bytes_moved_note": "PMC traffic when collected on this matrix, else 10*nnz + 44*n (16-bit column stream)",
+            "traffic_source": traffic_note,
             "measured_stream_read": {"GB/s": stream_gbs, "us": k_us["stream_read"], "bytes": 12 * nnz,
                                      "what": "16-byte-load read of the operator's values + column indices on this box",
                                      "frac_of_it": achieved / stream_gbs},

@@ -317,6 +317,11 @@ def test_bench_line_keeps_its_contract_on_a_small_mesh(hip):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["us_per_launch"] > 0 and "in-loop" in r["timing"] and r["assembly"]["default_mode"] == "row_gather"
     assert r["jacobi_pcg_iteration"]["bytes"] == 12 * out["config"]["nnz"] + 84 * n
+    # roofline.traffic: measured in this very invocation (child runs under rocprofv3 --pmc) - or the line says why not
+    if r["traffic"] is not None:
+        assert r["traffic_source"].startswith("measured in this run") and 0.3 < r["traffic"] / r["bytes_per_launch"] < 3.0
+    else:
+        assert "not available" in r["traffic_source"] or "not measured" in r["traffic_source"]
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == out["unit"]
     assert out["config"]["gpu_over_cpu"] == pytest.approx(out["value"] / c["value"])
