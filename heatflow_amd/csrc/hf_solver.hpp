@@ -276,7 +276,9 @@ template <int SM, typename VT>
 void launch_stream_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y, double* part0, const double* bvec,
                      double* conv_part) {
   const int npart = c->P;                  // the consumers of part0 sum c->P slots: never more workgroups than that
-  int grid = std::min(m.nchunks, npart);
+  // without partial sums to write (SM 0) the grid may exceed the partial slots: HEATFLOW_STREAM_GRID (A/B; default MAXP)
+  static const int grid_cap = std::getenv("HEATFLOW_STREAM_GRID") ? std::atoi(std::getenv("HEATFLOW_STREAM_GRID")) : MAXP;
+  int grid = std::min(m.nchunks, (SM == 0 && part0 == nullptr) ? std::max(grid_cap, 1) : npart);
   if (grid >= 64) grid &= ~7;
 #define HF_STREAM_ARGS2 m.nrow, m.nchunks, m.rpc, m.ptr, m.idx, val, x, y, c->d_scal, part0, bvec, static_cast<const double*>(nullptr), \
                         static_cast<double*>(nullptr), static_cast<double*>(nullptr), conv_part, 0.0, npart, 0
@@ -299,7 +301,8 @@ template <int VMODE, typename VT>
 void launch_vec_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y) {
   if (m.rpc > 0) {
     constexpr int SM = VMODE == 0 ? 0 : 6;
-    int grid = std::min(m.nchunks, MAXP);
+    static const int grid_cap = std::getenv("HEATFLOW_STREAM_GRID") ? std::atoi(std::getenv("HEATFLOW_STREAM_GRID")) : MAXP;
+    int grid = std::min(m.nchunks, std::max(grid_cap, 1));
     if (grid >= 64) grid &= ~7;
 #define HF_STREAM_ARGS m.nrow, m.nchunks, m.rpc, m.ptr, m.idx, val, x, y, c->d_scal, static_cast<double*>(nullptr),                       \
                        static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), static_cast<double*>(nullptr),   \
