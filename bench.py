@@ -438,6 +438,42 @@ def live_traffic(kind, kernel_regex, extra_args=()):
         "measured in this run: child runs of bench.py under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, (2*FETCH_SIZE + WRITE_SIZE)*1024, p90 over the launches"
 
 
+class SideGuard:
+    """Deadline for a side measurement that runs collectives AFTER the headline is measured (N > 1): if it has not been
+    disarmed in time, rank 0 writes the headline's line with the failure noted in the side measurement's place and every
+    rank ends its process (exit code 0: the line is complete) - before the process group's own watchdog aborts the job."""
+
+    def __init__(self, out, emit, seconds):
+        import threading
+        self.lock, self.state = threading.Lock(), "armed"
+        self.out, self.emit, self.seconds = out, emit, seconds
+        self.timer = threading.Timer(seconds, self._expired)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _expired(self):
+        with self.lock:
+            if self.state != "armed":
+                return
+            self.state = "expired"
+        sys.stderr.write(f"bench.py: side measurement not finished after {self.seconds:.0f} s: reporting the headline without it\n")
+        if self.out is not None:
+            self.out["config"]["sweep64"] = {"error": f"not finished after {self.seconds:.0f} s (collective or rank stuck); headline unaffected"}
+            self.out.setdefault("cpu_baseline", None)
+            self.emit(self.out)
+        sys.stderr.flush()
+        os._exit(0)
+
+    def disarm(self):
+        """True if the guard was still armed (the caller goes on), False if it has fired."""
+        with self.lock:
+            if self.state != "armed":
+                return False
+            self.state = "disarmed"
+        self.timer.cancel()
+        return True
+
+
 class Ranks:
     """The process group of this run (a world of one without torch.distributed)."""
 
@@ -819,19 +855,6 @@ def main(argv=None):
                   "pcg_iters_per_step_mean": float(np.mean(itj)), "value": n * args.jacobi_steps / tj}
     prob.close()
 
-    # ---- side measurements: the C5 sweep (every N), the HBM-resident roofline point (N = 1)
-    # (the headline's timing and every collective it needs are done: a failure of a side measurement is reported in its place,
-    # it does not take the line with it)
-    sweep = None
-    if args.sweep_points > 0:
-        try:
-            sweep = run_sweep64(ranks, args.sweep_points, 100, max(1, args.warmup), args.sweep_concurrent, args.sweep_batch)
-        except BaseException as e:          # noqa: BLE001 - SystemExit of a failed point included
-            sys.stderr.write(f"bench.py: the C5 side measurement failed on rank {rank}: {type(e).__name__}: {e}\n")
-            sweep = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
-    hbm = hbm_resident_point(args.hbm_scale, dev_index, 3) if (world == 1 and args.hbm_scale > 0) else None
-    batch_roof = batch_head_roofline(dev_index, args.sweep_batch, traffic_mode="file" if args.traffic == "live" else args.traffic) if (world == 1 and sweep is not None and "error" not in sweep and args.batch_roofline and args.sweep_batch > 1) else None
-
     if rank == 0:
         out = dict(common, metric="DOF-updates/s (timesteps/s x nDOF) on geballe_with_diamond",
                    value=world * n * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, scaling="weak")
@@ -862,7 +885,7 @@ def main(argv=None):
             "measured_stream_read": {"GB/s": stream_gbs, "us": k_us["stream_read"], "bytes": 12 * nnz,
                                      "what": "16-byte-load read of the operator's values + column indices on this box",
                                      "frac_of_it": achieved / stream_gbs},
-            "assembly": asm_roof, "hbm_resident": hbm}
+            "assembly": asm_roof, "hbm_resident": None}
         if jacobi is not None:
             # the whole Jacobi-PCG iteration = iteration head + update, 12*nnz + 84*n bytes, over the time the
             # loop really spends per iteration (steps incl. right-hand side and start vector / iterations)
@@ -877,6 +900,25 @@ def main(argv=None):
             out["config"]["amg"] = dict(amg_info, precision=PRECISION_TEXT)
         if jacobi is not None:
             out["config"]["jacobi_pcg"] = jacobi
+    # ---- side measurements: the C5 sweep (every N), the HBM-resident roofline point (N = 1)
+    # (the headline's timing and every collective it needs are done: a failure of a side measurement is reported in its place,
+    # it does not take the line with it.  N > 1: the sweep's collectives have a deadline of their own - a rank that hangs in one
+    # would otherwise end in the process group's watchdog abort and take the finished headline with it)
+    sweep = None
+    if args.sweep_points > 0:
+        guard = SideGuard(out if rank == 0 else None, emit, float(os.environ.get("HEATFLOW_BENCH_SIDE_TIMEOUT_S", "150"))) if world > 1 else None
+        try:
+            sweep = run_sweep64(ranks, args.sweep_points, 100, max(1, args.warmup), args.sweep_concurrent, args.sweep_batch)
+        except BaseException as e:          # noqa: BLE001 - SystemExit of a failed point included
+            sys.stderr.write(f"bench.py: the C5 side measurement failed on rank {rank}: {type(e).__name__}: {e}\n")
+            sweep = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
+        if guard is not None and not guard.disarm():
+            return 0                          # the guard has written the line (and is ending the process)
+    hbm = hbm_resident_point(args.hbm_scale, dev_index, 3) if (world == 1 and args.hbm_scale > 0) else None
+    batch_roof = batch_head_roofline(dev_index, args.sweep_batch, traffic_mode="file" if args.traffic == "live" else args.traffic) if (world == 1 and sweep is not None and "error" not in sweep and args.batch_roofline and args.sweep_batch > 1) else None
+
+    if rank == 0:
+        out["roofline"]["hbm_resident"] = hbm
         if sweep is not None and "error" in sweep:
             out["config"]["sweep64"] = sweep
         elif sweep is not None:
