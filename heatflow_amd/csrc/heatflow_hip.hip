@@ -1357,3 +1357,10 @@ int hf_last_gpu_ms(hf_ctx* ctx, double* ms) {
 }
 
 }  // extern "C"
+
+#if HF_PHASE_CLOCK >= 0
+// measurement builds only (see hf_kernels.hpp): the phase stamps of the last k_spmv<HF_PHASE_CLOCK, C16> launch
+extern "C" int hf_debug_phases(unsigned long long* out /* MAXP * 16 */) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * MAXP * 16) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -600,6 +600,28 @@ struct ColComp { const int32_t* dptr; const int32_t* dict; const uint16_t* id; i
 #ifndef HF_NT_STREAM
 #define HF_NT_STREAM 0
 #endif
+#ifndef HF_PIPE
+#define HF_PIPE 1      // chunk pipeline: 1 = single-precision operators (the transfer operators), 2 = all, 0 = none (A/B builds)
+#endif
+// HF_PHASE_CLOCK=<mode> (measurement builds only, scripts/phase_clock.py): lane 0 of every workgroup of k_spmv<mode, C16>
+// stamps the 100 MHz clock at its phase boundaries (entry, then per chunk: operand slice staged, products parked, rows
+// summed) into g_phase[workgroup][16]; hf_debug_phases copies the table out
+#ifndef HF_PHASE_CLOCK
+#define HF_PHASE_CLOCK -1
+#endif
+#if HF_PHASE_CLOCK >= 0
+#ifndef HF_PHASE_CONV
+#define HF_PHASE_CONV 0   // MODE 0 only: 1 = the launch that carries the convergence test (fused restriction of the finest level)
+#endif
+__device__ unsigned long long g_phase[MAXP * 16];
+#define HF_STAMP(slot)                                                                                   \
+  do {                                                                                                   \
+    if (MODE == HF_PHASE_CLOCK && C16 && (MODE != 0 || (part2 != nullptr) == (HF_PHASE_CONV != 0)) && threadIdx.x == 0 && (slot) < 16) \
+      g_phase[blockIdx.x * 16 + (slot)] = wall_clock64();                                                \
+  } while (0)
+#else
+#define HF_STAMP(slot) do { } while (0)
+#endif
 template <typename T>
 __device__ __forceinline__ T stream_load(const T* p) {
 #if HF_NT_STREAM
@@ -609,8 +631,8 @@ __device__ __forceinline__ T stream_load(const T* p) {
 #endif
 }
 
-template <int MODE, bool C16 = false, typename VT = double>
-__global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows per chunk, <= TS */,
+template <int MODE, bool C16 = false, typename VT = double, int UN = 8>
+__global__ __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_spmv(int n, int nchunks, int rpc /* rows per chunk, <= TS */,
                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                               const VT* __restrict__ vals, const double* __restrict__ x,
                                               double* __restrict__ y, Scal* __restrict__ scal,
@@ -668,29 +690,202 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
     if (conv) return;
   }
   const ChunkIter sched(nchunks);
-  for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
+  HF_STAMP(0);
+  int stamp_at = 1;
+  (void)stamp_at;
+  // Chunks of fewer rows than threads (transfer operators with long rows, MODE 0 / 6 / 7 only): tpr = TS / rpc lanes
+  // share a row's sum, so the row-sum phase uses every lane
+  const int tpr = (MODE == 0 || MODE == 6 || MODE == 7) ? TS / rpc : 1;
+  const int prel = static_cast<int>(threadIdx.x) / tpr;
+  const int psub = static_cast<int>(threadIdx.x) % tpr;
+  struct RowOps { double b, d, y, p, x; };
+  // row-wise epilogue operands, requested early so that their latency hides under the chunk's stream.  Unconditional loads
+  // at a clamped row: a load under a divergent branch makes the compiler's wait counters inexact - every later wait
+  // would then cover all loads in flight, the prefetched ones of the next chunk included
+  auto row_operands = [&](int prc, bool from_slice) {
+    RowOps e{0.0, 0.0, 0.0, 0.0, 0.0};
+    if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8) e.b = bvec[prc];
+    if (MODE == 2 || MODE == 4 || MODE == 5) e.d = dinv[prc];
+    if (MODE == 6 || (MODE == 9 && !first9)) e.y = y[prc];
+    if (MODE == 9 && !first9) e.p = pvec[prc];
+    if ((MODE == 4 || MODE == 8 || MODE == 9) && !from_slice) e.x = x[prc];
+    return e;
+  };
+  // the chunk's products are parked in sprod: row sums in CSR order and the mode's epilogue
+  auto rows_phase = [&](bool pin, int prow, int pa, int pb, const RowOps& e) {
+    if ((MODE == 0 || MODE == 6 || MODE == 7) && tpr > 1) {
+      // tpr is a power of two <= 16 (rpc >= 32): the lanes of a row are neighbours inside one wavefront
+      double s = 0.0;
+      if (pin)
+        for (int j = pa + psub; j < pb; j += tpr) s += sprod[j];
+      for (int o = tpr >> 1; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+      if (pin && psub == 0) {
+        y[prow] = (MODE == 6) ? e.y + s : s;
+        if (MODE == 7) acc0 += e.b * s;
+      }
+    } else if (pin) {
+      const int row = prow;
+      double s = 0.0;
+      for (int j = pa; j < pb; ++j) s += sprod[j];
+      if (MODE == 0) {
+        y[row] = s;
+      } else if (MODE == 2) {
+        const double ri = e.b - s;
+        const double zi = e.d * ri;
+        y[row] = ri;
+        pvec[row] = zi;
+        acc0 += ri * zi;
+        acc1 += zi * zi;
+        acc2 += (e.d * e.b) * (e.d * e.b);
+      } else if (MODE == 3) {
+        y[row] = e.b - s;
+      } else if (MODE == 4) {
+        const double yi = e.x + w * e.d * (e.b - s);
+        y[row] = yi;
+        acc0 += e.b * yi;
+      } else if (MODE == 5) {
+        const double ri = e.b - s;
+        y[row] = ri;
+        pvec[row] = w * e.d * ri;
+        acc1 += (e.d * ri) * (e.d * ri);
+        acc2 += (e.d * e.b) * (e.d * e.b);
+      } else if (MODE == 7) {
+        y[row] = s;
+        acc0 += e.b * s;
+      } else if (MODE == 6) {
+        y[row] = e.y + s;
+      } else if (MODE == 8) {
+        y[row] = s;
+        pvec[row] = 2.0 * e.x - e.b;
+      } else {
+        const double api = first9 ? s : s + beta * e.y;          // first iteration: p = z, Ap = A z
+        const double pi = first9 ? e.x : e.x + beta * e.p;
+        y[row] = api;
+        pvec[row] = pi;
+        acc0 += pi * api;
+      }
+    }
+  };
+  if (C16 && (HF_PIPE == 2 || (HF_PIPE == 1 && sizeof(VT) == 4))) {
+    // Software pipeline over the workgroup's chunks.  A chunk needs, in dependent order: its bounds -> the head of its
+    // column list and its matrix stream (values, 16-bit positions) -> the gathered operand slice.  While chunk c is
+    // worked on, the bounds, the list head and the first UN * TS entries of the stream of chunk c+1 are already in flight
+    // (registers), so c+1 starts with its operand gathers and finds its stream landed.  Every load of the pipeline is
+    // unconditional (clamped or parked index) - see row_operands.
+    struct Bounds { int k0, k1, d0, d1; };
+    auto bounds = [&](int ch) {
+      Bounds q;
+      const int a0 = ch * rpc, a1 = min(n, a0 + rpc);
+      q.k0 = rowptr[a0]; q.k1 = rowptr[a1];
+      q.d0 = comp.dptr[ch]; q.d1 = comp.dptr[ch + 1];
+      return q;
+    };
+    int lhead[HF_STAGE_U];        // list head of the chunk about to start
+    double v[UN];                 // its first UN * TS stream entries
+    int id[UN];
+    auto heads = [&](const Bounds& q, bool live) {
+      // !live (no further chunk; q = the current one): every wavefront re-reads the chunk's first 32 entries, results
+      // unused.  The offset stays a per-lane value on purpose: with a uniform parked index the compiler turns the loads
+      // into scalar ones behind a branch and waits for every load in flight there.
+      const int dl = q.d1 - 1, kl = max(q.k1 - 1, 0);
+      const int t = static_cast<int>(threadIdx.x);
+#pragma unroll
+      for (int u = 0; u < HF_STAGE_U; ++u) lhead[u] = comp.dict[min(q.d0 + (live ? t + u * TS : (t & 31)), dl)];
+      __builtin_amdgcn_sched_barrier(0);   // list head first: the next chunk's gathers wait for it and for nothing younger
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int kk = min(q.k0 + (live ? t + u * TS : (t & 31)), kl);
+        v[u] = static_cast<double>(stream_load(&vals[kk]));
+        id[u] = static_cast<int>(stream_load(&comp.id[kk]));
+      }
+    };
+    double* xd = sprod + comp.xd_off;
+    Bounds cur = bounds(min(sched.chunk, nchunks - 1));
+    heads(cur, sched.chunk < sched.end);
+    for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
+      const bool more = chunk + sched.step < sched.end;
+      const int r0 = chunk * rpc, r1 = min(n, r0 + rpc);
+      const int k0 = cur.k0, k1 = cur.k1, d0 = cur.d0, nd = cur.d1 - cur.d0;
+      const int prow = r0 + prel;
+      const bool pin = prow < r1;
+      const int prc = min(prow, r1 - 1);
+      // (1) operand gathers of the list head, then the next chunk's bounds, this lane's row bounds and row operands
+      int c0[HF_STAGE_U];
+      double x0[HF_STAGE_U];
+#pragma unroll
+      for (int u = 0; u < HF_STAGE_U; ++u) { c0[u] = lhead[u]; x0[u] = x[c0[u]]; }
+      const Bounds nxt = bounds(more ? chunk + sched.step : chunk);
+      const int pa = rowptr[prc] - k0, pb = rowptr[prc + 1] - k0;
+      RowOps e = row_operands(prc, comp.own != 0);
+      // (2) operand slice into LDS
+#pragma unroll
+      for (int u = 0; u < HF_STAGE_U; ++u) {
+        const int i = static_cast<int>(threadIdx.x) + u * TS;
+        if (i < nd) {
+          xd[i] = x0[u];
+          if ((MODE == 4 || MODE == 8 || MODE == 9) && c0[u] == r0) s_own = i;
+        }
+      }
+      for (int i = threadIdx.x + HF_STAGE_U * TS; i < nd; i += HF_STAGE_U * TS) {   // lists longer than the head (rare)
+        int c[HF_STAGE_U];
+        double xv[HF_STAGE_U];
+#pragma unroll
+        for (int u = 0; u < HF_STAGE_U; ++u) c[u] = comp.dict[d0 + min(i + u * TS, nd - 1)];
+#pragma unroll
+        for (int u = 0; u < HF_STAGE_U; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < HF_STAGE_U; ++u)
+          if (i + u * TS < nd) {
+            xd[i + u * TS] = xv[u];
+            if ((MODE == 4 || MODE == 8 || MODE == 9) && c[u] == r0) s_own = i + u * TS;
+          }
+      }
+      __syncthreads();
+      HF_STAMP(stamp_at); ++stamp_at;
+      if ((MODE == 4 || MODE == 8 || MODE == 9) && comp.own && pin) e.x = xd[s_own + (prow - r0)];
+      // (3) products in stream order
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int kk = k0 + static_cast<int>(threadIdx.x) + u * TS;
+        if (kk < k1) sprod[kk - k0] = v[u] * xd[id[u]];
+      }
+      for (int kb = k0 + UN * TS; kb < k1; kb += UN * TS) {     // chunks longer than UN * TS entries (rare)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int kk = min(kb + static_cast<int>(threadIdx.x) + u * TS, k1 - 1);
+          v[u] = static_cast<double>(stream_load(&vals[kk]));
+          id[u] = static_cast<int>(stream_load(&comp.id[kk]));
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int kk = kb + static_cast<int>(threadIdx.x) + u * TS;
+          if (kk < k1) sprod[kk - k0] = v[u] * xd[id[u]];
+        }
+      }
+      // (4) the next chunk's list head and stream head go out; they land while the rows are summed and stored
+      heads(nxt, more);
+      __syncthreads();
+      HF_STAMP(stamp_at); ++stamp_at;
+      rows_phase(pin, prow, pa, pb, e);
+      __syncthreads();
+      HF_STAMP(stamp_at); ++stamp_at;
+      cur = nxt;
+    }
+  } else {
+  const ChunkIter& sched_ = sched;
+  for (int chunk = sched_.chunk; chunk < sched_.end; chunk += sched_.step) {
     const int r0 = chunk * rpc;
     const int r1 = min(n, r0 + rpc);
     const int k0 = rowptr[r0];
     const int k1 = rowptr[r1];
-    // row-wise epilogue operands are requested before the product stream so their latency hides under it.
-    // Chunks of fewer rows than threads (transfer operators with long rows, MODE 0 / 6 only): tpr = TS / rpc lanes
-    // share a row's sum, so the row-sum phase uses every lane
-    const int tpr = (MODE == 0 || MODE == 6 || MODE == 7) ? TS / rpc : 1;
-    const int prow = r0 + static_cast<int>(threadIdx.x) / tpr;
-    const int psub = static_cast<int>(threadIdx.x) % tpr;
+    const int prow = r0 + prel;
     const bool pin = prow < r1;
     int pa = 0, pb = 0;
-    double e_b = 0.0, e_d = 0.0, e_y = 0.0, e_p = 0.0, e_x = 0.0;
     if (pin) {
       pa = rowptr[prow] - k0;
       pb = rowptr[prow + 1] - k0;
-      if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8) e_b = bvec[prow];
-      if (MODE == 2 || MODE == 4 || MODE == 5) e_d = dinv[prow];
-      if (MODE == 6 || (MODE == 9 && !first9)) e_y = y[prow];
-      if (MODE == 9 && !first9) e_p = pvec[prow];
-      if ((MODE == 4 || MODE == 8 || MODE == 9) && !(C16 && comp.own)) e_x = x[prow];
     }
+    RowOps e = row_operands(min(prow, r1 - 1), C16 && comp.own != 0);
     if (C16) {
       // first batch of values / 16-bit ids is requested before the operand slice is staged, so both latencies overlap
       double* xd = sprod + comp.xd_off;
@@ -722,7 +917,7 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
           }
       }
       __syncthreads();
-      if ((MODE == 4 || MODE == 8 || MODE == 9) && comp.own && pin) e_x = xd[s_own + (prow - r0)];
+      if ((MODE == 4 || MODE == 8 || MODE == 9) && comp.own && pin) e.x = xd[s_own + (prow - r0)];
       while (k < k1) {
         const int kn = k + HF_UNROLL * TS;
         double vn[HF_UNROLL];
@@ -759,59 +954,9 @@ __global__ __launch_bounds__(TS) void k_spmv(int n, int nchunks, int rpc /* rows
       }
     }
     __syncthreads();
-    if ((MODE == 0 || MODE == 6 || MODE == 7) && tpr > 1) {
-      // tpr is a power of two <= 16 (rpc >= 32): the lanes of a row are neighbours inside one wavefront
-      double s = 0.0;
-      if (pin)
-        for (int j = pa + psub; j < pb; j += tpr) s += sprod[j];
-      for (int o = tpr >> 1; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-      if (pin && psub == 0) {
-        y[prow] = (MODE == 6) ? e_y + s : s;
-        if (MODE == 7) acc0 += e_b * s;
-      }
-    } else if (pin) {
-      const int row = prow;
-      double s = 0.0;
-      for (int j = pa; j < pb; ++j) s += sprod[j];
-      if (MODE == 0) {
-        y[row] = s;
-      } else if (MODE == 2) {
-        const double ri = e_b - s;
-        const double zi = e_d * ri;
-        y[row] = ri;
-        pvec[row] = zi;
-        acc0 += ri * zi;
-        acc1 += zi * zi;
-        acc2 += (e_d * e_b) * (e_d * e_b);
-      } else if (MODE == 3) {
-        y[row] = e_b - s;
-      } else if (MODE == 4) {
-        const double yi = e_x + w * e_d * (e_b - s);
-        y[row] = yi;
-        acc0 += e_b * yi;
-      } else if (MODE == 5) {
-        const double ri = e_b - s;
-        y[row] = ri;
-        pvec[row] = w * e_d * ri;
-        acc1 += (e_d * ri) * (e_d * ri);
-        acc2 += (e_d * e_b) * (e_d * e_b);
-      } else if (MODE == 7) {
-        y[row] = s;
-        acc0 += e_b * s;
-      } else if (MODE == 6) {
-        y[row] = e_y + s;
-      } else if (MODE == 8) {
-        y[row] = s;
-        pvec[row] = 2.0 * e_x - e_b;
-      } else {
-        const double api = first9 ? s : s + beta * e_y;          // first iteration: p = z, Ap = A z
-        const double pi = first9 ? e_x : e_x + beta * e_p;
-        y[row] = api;
-        pvec[row] = pi;
-        acc0 += pi * api;
-      }
-    }
+    rows_phase(pin, prow, pa, pb, e);
     __syncthreads();
+  }
   }
   // consumers sum `npart` slots in a fixed order; this launch has fewer workgroups, the rest are zeros
   if (MODE == 2 || MODE == 7 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {
