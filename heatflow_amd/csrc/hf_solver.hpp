@@ -282,7 +282,11 @@ void launch_stream_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x,
   if (grid >= 64) grid &= ~7;
 #define HF_STREAM_ARGS2 m.nrow, m.nchunks, m.rpc, m.ptr, m.idx, val, x, y, c->d_scal, part0, bvec, static_cast<const double*>(nullptr), \
                         static_cast<double*>(nullptr), static_cast<double*>(nullptr), conv_part, 0.0, npart, 0
-  if (m.cid != nullptr)
+  // UN = stream entries per lane the chunk pipeline keeps in flight (single-precision operators): short chunks take 4
+  if (m.cid != nullptr && sizeof(VT) == 4 && m.chunk_nnz <= 4 * TS)
+    hipLaunchKernelGGL((k_spmv<SM, true, VT, 4>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz + m.max_dict) * 8, c->stream,
+                       HF_STREAM_ARGS2, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz, 0});
+  else if (m.cid != nullptr)
     hipLaunchKernelGGL((k_spmv<SM, true, VT>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz + m.max_dict) * 8, c->stream,
                        HF_STREAM_ARGS2, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz, 0});
   else
@@ -307,7 +311,10 @@ void launch_vec_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, do
 #define HF_STREAM_ARGS m.nrow, m.nchunks, m.rpc, m.ptr, m.idx, val, x, y, c->d_scal, static_cast<double*>(nullptr),                       \
                        static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), static_cast<double*>(nullptr),   \
                        static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0.0, 0, 0
-    if (m.cid != nullptr)
+    if (m.cid != nullptr && sizeof(VT) == 4 && m.chunk_nnz <= 4 * TS)
+      hipLaunchKernelGGL((k_spmv<SM, true, VT, 4>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz + m.max_dict) * 8, c->stream,
+                         HF_STREAM_ARGS, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz, 0});
+    else if (m.cid != nullptr)
       hipLaunchKernelGGL((k_spmv<SM, true, VT>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz + m.max_dict) * 8, c->stream,
                          HF_STREAM_ARGS, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz, 0});
     else
