@@ -23,7 +23,7 @@ namespace {
 // mesh.msh in every worker instead).
 struct MeshTables {
   std::vector<int32_t> rowptr, colidx;
-  ColDict spmv;                 // compressed columns per TS-row SpMV chunk
+  ColDict spmv;                 // compressed columns per SRPC-row SpMV chunk
   RowGather rg;                 // row-gather assembly lists per RBA-row block (rg.ok = false: not available)
   std::vector<char> tag_used;   // cell tags present in the mesh (index = tag)
   int max_blk_nnz = 0;
@@ -48,12 +48,12 @@ int install_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int
   ctx->nblk_a = (n + RBA - 1) / RBA;
   ctx->P = std::min(ctx->nchunks, MAXP);
   if (ctx->P >= 64) ctx->P &= ~7;          // multiple of 8: one equal group of workgroups per XCD
-  ctx->nchunks_s = (n + TS - 1) / TS;
+  ctx->nchunks_s = (n + SRPC - 1) / SRPC;
   ctx->Ps = std::min(ctx->nchunks_s, MAXP);
   if (ctx->Ps >= 64) ctx->Ps &= ~7;
   ctx->max_chunk_nnz_s = 0;
   for (int c = 0; c < ctx->nchunks_s; ++c)
-    ctx->max_chunk_nnz_s = std::max(ctx->max_chunk_nnz_s, T.rowptr[std::min<int64_t>(n, (c + 1LL) * TS)] - T.rowptr[static_cast<size_t>(c) * TS]);
+    ctx->max_chunk_nnz_s = std::max(ctx->max_chunk_nnz_s, T.rowptr[std::min<int64_t>(n, (c + 1LL) * SRPC)] - T.rowptr[static_cast<size_t>(c) * SRPC]);
   ctx->max_cdict = T.spmv.max_dict;
   ctx->c16 = true;
   if (const char* e = std::getenv("HEATFLOW_SPMV_C16")) ctx->c16 = (e[0] != '0');
@@ -61,7 +61,7 @@ int install_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int
   // own rows of a chunk contiguous in its sorted column list <=> every row stores its diagonal (P1 patterns do)
   ctx->cdict_own = static_cast<int>(T.spmv.ptr.size()) == ctx->nchunks_s + 1;
   for (int c = 0; c < ctx->nchunks_s && ctx->cdict_own; ++c) {
-    const int32_t r0 = c * TS, r1 = std::min<int32_t>(n, r0 + TS);
+    const int32_t r0 = c * SRPC, r1 = std::min<int32_t>(n, r0 + SRPC);
     const int32_t* lo = T.spmv.dict.data() + T.spmv.ptr[c];
     const int32_t* hi = T.spmv.dict.data() + T.spmv.ptr[c + 1];
     const int32_t* at = std::lower_bound(lo, hi, r0);
@@ -192,7 +192,7 @@ int write_mesh_tables(hf_ctx* ctx, unsigned char* dst) {
   list_sections(ctx, s, h.count);
   std::memcpy(h.magic, BLOB_MAGIC, 8);
   h.total_bytes = mesh_tables_bytes(ctx);
-  h.nnz = ctx->nnz; h.n = ctx->n; h.ne = ctx->ne; h.rba = RBA; h.ts = TS; h.max_blk_nnz = ctx->max_blk_nnz;
+  h.nnz = ctx->nnz; h.n = ctx->n; h.ne = ctx->ne; h.rba = RBA; h.ts = SRPC; h.max_blk_nnz = ctx->max_blk_nnz;
   h.tab_len = ctx->tab_len; h.rg_ok = ctx->rg_ok ? 1 : 0; h.rg_max_dict = ctx->rg_max_dict; h.spmv_max_dict = ctx->max_cdict;
   std::memset(dst, 0, static_cast<size_t>(h.total_bytes));
   std::memcpy(dst, &h, sizeof h);
@@ -226,7 +226,7 @@ int parse_mesh_tables(hf_ctx* ctx, const unsigned char* blob, int64_t bytes, int
   if (std::memcmp(h.magic, BLOB_MAGIC, 8) != 0) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: not a pattern blob of this library version");
   if (h.total_bytes != bytes) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: blob says %lld bytes, %lld given", (long long)h.total_bytes, (long long)bytes);
   if (h.n != n || h.ne != ne) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: blob was exported for a mesh of %d nodes / %d triangles, not %d / %d", h.n, h.ne, n, ne);
-  if (h.rba != RBA || h.ts != TS) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: blob built for other block sizes");
+  if (h.rba != RBA || h.ts != SRPC) return fail(ctx, HF_ERR_ARG, "hf_set_mesh_prebuilt: blob built for other block sizes");
   size_t at = pad16(sizeof(BlobHeader));
   std::vector<int4> hdr;
   bool ok = take_section(blob, bytes, at, h.count[0], T.rowptr) && take_section(blob, bytes, at, h.count[1], T.colidx) &&
@@ -235,7 +235,7 @@ int parse_mesh_tables(hf_ctx* ctx, const unsigned char* blob, int64_t bytes, int
             take_section(blob, bytes, at, h.count[6], T.rg.hdr) && take_section(blob, bytes, at, h.count[7], T.rg.ell) &&
             take_section(blob, bytes, at, h.count[8], T.rg.tags) && take_section(blob, bytes, at, h.count[9], T.rg.cols.dict) &&
             take_section(blob, bytes, at, h.count[10], T.rg.cols.id);
-  const int nblk = (n + RBA - 1) / RBA, nch = (n + TS - 1) / TS;
+  const int nblk = (n + RBA - 1) / RBA, nch = (n + SRPC - 1) / SRPC;
   ok = ok && T.rowptr.size() == static_cast<size_t>(n) + 1 && T.rowptr[0] == 0 && T.rowptr[n] == h.nnz &&
        T.colidx.size() == static_cast<size_t>(h.nnz) && T.spmv.ptr.size() == static_cast<size_t>(nch) + 1 &&
        T.spmv.id.size() == T.colidx.size() && static_cast<int>(T.tag_used.size()) == h.tab_len && h.tab_len > 0 &&
@@ -251,7 +251,7 @@ int parse_mesh_tables(hf_ctx* ctx, const unsigned char* blob, int64_t bytes, int
   for (int c = 0; c < nch && ok; ++c) {
     const int nd = T.spmv.ptr[c + 1] - T.spmv.ptr[c];
     ok = nd > 0 && nd <= h.spmv_max_dict;
-    for (int32_t k = T.rowptr[static_cast<size_t>(c) * TS]; k < T.rowptr[std::min<int64_t>(n, (c + 1LL) * TS)] && ok; ++k) ok = T.spmv.id[k] < nd;
+    for (int32_t k = T.rowptr[static_cast<size_t>(c) * SRPC]; k < T.rowptr[std::min<int64_t>(n, (c + 1LL) * SRPC)] && ok; ++k) ok = T.spmv.id[k] < nd;
   }
   if (ok && h.rg_ok) {
     for (size_t k = 0; k < T.rg.cols.dict.size() && ok; ++k) ok = T.rg.cols.dict[k] >= 0 && T.rg.cols.dict[k] < n;
@@ -480,7 +480,7 @@ int hf_set_mesh(hf_ctx* ctx, int32_t n, int32_t ne, const double* zr, const int3
   lap("+ csr pattern");
   build_rowgather(n, ne, tri, tag, P);
   lap("+ row-gather lists");
-  if (!build_coldict(P.rowptr, P.colidx, n, TS, T.spmv)) return fail(ctx, HF_ERR_ARG, "an SpMV chunk touches more than 65535 columns (16-bit positions)");
+  if (!build_coldict(P.rowptr, P.colidx, n, SRPC, T.spmv)) return fail(ctx, HF_ERR_ARG, "an SpMV chunk touches more than 65535 columns (16-bit positions)");
   lap("+ spmv column lists");
   T.rowptr.swap(P.rowptr);
   T.colidx.swap(P.colidx);

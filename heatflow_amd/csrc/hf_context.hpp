@@ -39,6 +39,15 @@ constexpr int NCOL = 32;       // max colours per row block (uint32 mask)
 constexpr int MAXP = 1024;     // max workgroups per launch = partial-sum slots per array
 constexpr int MAXRESP = 4;     // boundary-response directions kept per operator
 constexpr int TS = 512;        // SpMV workgroup: 512 threads = 8 wavefronts own 512 consecutive rows per chunk
+// rows per chunk of the fine operator's LDS-staged SpMV (a workgroup of TS threads, one row per lane in the row phase;
+// fewer rows than TS: more, shorter chunks per workgroup for the chunk pipeline) and its stream entries per lane in flight
+#ifndef HF_SPMV_RPC
+#define HF_SPMV_RPC 512
+#endif
+#ifndef HF_SPMV_UN
+#define HF_SPMV_UN 8
+#endif
+constexpr int SRPC = HF_SPMV_RPC;
                                // (4 such workgroups per CU = 32 waves/CU; measured 20 % faster than 256x16)
 
 // Host-visible progress of the running solve (pinned, mapped memory): written by the one thread that changes the

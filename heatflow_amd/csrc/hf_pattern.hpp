@@ -411,13 +411,13 @@ void launch_spmv(hf_ctx* c, const VT* vals, const double* x, double* y, double* 
   // With events: the launch carries them (hipExtLaunchKernelGGL), so they bracket the kernel's own
   // execution on the device - the same interval rocprofv3 reports - not the launch gap before it.
   const ColComp comp{c->d_cdict_ptr, c->d_cdict, c->d_cid, c->max_chunk_nnz_s, c->cdict_own ? 1 : 0};
-#define HF_SPMV_ARGS c->n, c->nchunks_s, static_cast<int>(TS), static_cast<const int32_t*>(c->d_rowptr),                    \
+#define HF_SPMV_ARGS c->n, c->nchunks_s, static_cast<int>(SRPC), static_cast<const int32_t*>(c->d_rowptr),                    \
                      static_cast<const int32_t*>(c->d_colidx), vals, x, y, (MODE == 0 ? nullptr : c->d_scal), part0, bvec,  \
                      dinv ? dinv : static_cast<const double*>(c->d_dinv), pvec, part1, part2, w, c->P, parity, comp
   const std::uint32_t smem = static_cast<std::uint32_t>(spmv_smem_bytes(c));
   if (c->c16) {
-    if (ev_start != nullptr) hipExtLaunchKernelGGL((k_spmv<MODE, true, VT>), dim3(c->Ps), dim3(TS), smem, c->stream, ev_start, ev_stop, 0u, HF_SPMV_ARGS);
-    else hipLaunchKernelGGL((k_spmv<MODE, true, VT>), dim3(c->Ps), dim3(TS), smem, c->stream, HF_SPMV_ARGS);
+    if (ev_start != nullptr) hipExtLaunchKernelGGL((k_spmv<MODE, true, VT, HF_SPMV_UN>), dim3(c->Ps), dim3(TS), smem, c->stream, ev_start, ev_stop, 0u, HF_SPMV_ARGS);
+    else hipLaunchKernelGGL((k_spmv<MODE, true, VT, HF_SPMV_UN>), dim3(c->Ps), dim3(TS), smem, c->stream, HF_SPMV_ARGS);
   } else {
     if (ev_start != nullptr) hipExtLaunchKernelGGL((k_spmv<MODE, false, VT>), dim3(c->Ps), dim3(TS), smem, c->stream, ev_start, ev_stop, 0u, HF_SPMV_ARGS);
     else hipLaunchKernelGGL((k_spmv<MODE, false, VT>), dim3(c->Ps), dim3(TS), smem, c->stream, HF_SPMV_ARGS);

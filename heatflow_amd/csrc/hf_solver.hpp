@@ -272,6 +272,10 @@ int build_amg(hf_ctx* ctx) {
 // sub-wave kernel otherwise.
 // LDS-staged kernel on an operator of the hierarchy in mode SM (0: y = A x, 7: y = A x with b.y partials), optional
 // early exit on the convergence partials `conv_part`.  The operator must be one the stream kernel runs (rpc > 0).
+// UN = stream entries per lane the chunk pipeline of k_spmv keeps in flight (single-precision operators): 4 where the
+// average chunk holds at most 3.5 per lane (a longer chunk takes its remainder in a second, exposed pass), else 8
+inline bool short_chunks(const DevCsr& m) { return m.nchunks > 0 && m.nnz <= static_cast<int64_t>(m.nchunks) * (7 * TS / 2); }
+
 template <int SM, typename VT>
 void launch_stream_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, double* y, double* part0, const double* bvec,
                      double* conv_part) {
@@ -282,8 +286,7 @@ void launch_stream_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x,
   if (grid >= 64) grid &= ~7;
 #define HF_STREAM_ARGS2 m.nrow, m.nchunks, m.rpc, m.ptr, m.idx, val, x, y, c->d_scal, part0, bvec, static_cast<const double*>(nullptr), \
                         static_cast<double*>(nullptr), static_cast<double*>(nullptr), conv_part, 0.0, npart, 0
-  // UN = stream entries per lane the chunk pipeline keeps in flight (single-precision operators): short chunks take 4
-  if (m.cid != nullptr && sizeof(VT) == 4 && m.chunk_nnz <= 4 * TS)
+  if (m.cid != nullptr && sizeof(VT) == 4 && short_chunks(m))
     hipLaunchKernelGGL((k_spmv<SM, true, VT, 4>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz + m.max_dict) * 8, c->stream,
                        HF_STREAM_ARGS2, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz, 0});
   else if (m.cid != nullptr)
@@ -311,7 +314,7 @@ void launch_vec_t(hf_ctx* c, const DevCsr& m, const VT* val, const double* x, do
 #define HF_STREAM_ARGS m.nrow, m.nchunks, m.rpc, m.ptr, m.idx, val, x, y, c->d_scal, static_cast<double*>(nullptr),                       \
                        static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), static_cast<double*>(nullptr),   \
                        static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0.0, 0, 0
-    if (m.cid != nullptr && sizeof(VT) == 4 && m.chunk_nnz <= 4 * TS)
+    if (m.cid != nullptr && sizeof(VT) == 4 && short_chunks(m))
       hipLaunchKernelGGL((k_spmv<SM, true, VT, 4>), dim3(grid), dim3(TS), static_cast<size_t>(m.chunk_nnz + m.max_dict) * 8, c->stream,
                          HF_STREAM_ARGS, ColComp{m.dptr, m.dict, m.cid, m.chunk_nnz, 0});
     else if (m.cid != nullptr)
