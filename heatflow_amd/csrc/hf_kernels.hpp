@@ -917,6 +917,7 @@ __global__ __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(8, 8))) void
           }
       }
       __syncthreads();
+      HF_STAMP(stamp_at); ++stamp_at;
       if ((MODE == 4 || MODE == 8 || MODE == 9) && comp.own && pin) e.x = xd[s_own + (prow - r0)];
       while (k < k1) {
         const int kn = k + HF_UNROLL * TS;
@@ -954,8 +955,10 @@ __global__ __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       }
     }
     __syncthreads();
+    HF_STAMP(stamp_at); ++stamp_at;
     rows_phase(pin, prow, pa, pb, e);
     __syncthreads();
+    HF_STAMP(stamp_at); ++stamp_at;
   }
   }
   // consumers sum `npart` slots in a fixed order; this launch has fewer workgroups, the rest are zeros
