@@ -409,6 +409,8 @@ def live_traffic(kind, kernel_regex, extra_args=()):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.isfile(exe):
         return None, "rocprofv3 not found"
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH")):
+        return None, "this run is itself under rocprofv3 (a nested profiler would inherit its preloaded tool library)"
     vals = {}
     tmp = tempfile.mkdtemp(prefix="hf_pmc_")
     try:

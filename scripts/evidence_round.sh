@@ -10,5 +10,5 @@ HEATFLOW_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload sweep64 > $O/${t
 { python scripts/gpu_probe.py 0.215 12 3 1 | grep -v "assemble mode" ; python scripts/gpu_probe.py 0.1075 12 3 1 | grep -v "assemble mode"; } > $O/${tag}_amg_large.txt 2>&1 || exit 1
 python scripts/pattern_share_probe.py 0.43 > $O/${tag}_pattern_share.txt 2>&1 || exit 1
 python scripts/amg_robustness.py > $O/${tag}_amg_robustness.txt 2>&1 || exit 1
-HEATFLOW_DEBUG=1 python scripts/gpu_probe.py 0.43 8 3 1 2>&1 | grep "\[amg\]" > $O/${tag}_amg_operators.txt
+HEATFLOW_DEBUG=1 python scripts/gpu_probe.py 0.43 8 3 1 2>&1 | grep "\[amg\]" | awk '!seen[$0]++' > $O/${tag}_amg_operators.txt
 tail -3 $O/${tag}_amg_large.txt

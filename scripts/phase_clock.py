@@ -33,6 +33,7 @@ def main():
     used = t[:, 0] > 0
     t = t[used]
     t0 = t[:, 0].min()
+    t[(t < t0) | (t > t0 + 1000.0)] = 0.0           # slots this launch did not write (stamps of earlier launches)
     nst = (t > 0).sum(axis=1)
     end = np.array([row[k - 1] for row, k in zip(t, nst)])
     print(f"== {label}: {used.sum()} workgroups stamped; first entry -> last exit {end.max() - t0:.2f} us; entries spread over "

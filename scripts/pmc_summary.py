@@ -18,6 +18,8 @@ def short(name):
     if m.group(1) == "k_spmv":
         targs = re.sub(r",\s*(true|false)", "", targs)             # k_spmv<9, true, double> (compressed columns) -> k_spmv<9>
         targs = re.sub(r",\s*double", "", targs).replace(", float", ",f32")   # single-precision transfer operators keep a tag
+        if "f32" not in targs:
+            targs = re.sub(r",\s*\d+>$", ">", targs)               # stream entries per lane (4 / 8): kept for the pipelined transfer operators only
     return m.group(1) + targs
 
 

@@ -8,8 +8,8 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-C3ARGS="--steps 20 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 3 --device-warmup-s 0.5"
-HBMARGS="--scale 0.1075 --precond jacobi --steps 2 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 0 --profile-steps 1 --device-warmup-s 0.5"
+C3ARGS="--traffic file --steps 20 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 3 --device-warmup-s 0.5"
+HBMARGS="--traffic file --scale 0.1075 --precond jacobi --steps 2 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 0 --profile-steps 1 --device-warmup-s 0.5"
 for what in "$@"; do
   case $what in
     c3)
@@ -21,11 +21,11 @@ for what in "$@"; do
       head -12 $O/prof_${tag}_hbm/run_kernel_stats.csv ;;
     pmc_c3)
       for c in FETCH_SIZE WRITE_SIZE; do
-        timeout -k 10 400 rocprofv3 --pmc $c -d $O/prof_${tag}_c3_$c -o run --output-format csv -- python3 $R/bench.py --steps 6 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 3 --profile-steps 0 > /dev/null 2> $O/prof_${tag}_c3_$c.err || exit 1
+        timeout -k 10 400 rocprofv3 --pmc $c -d $O/prof_${tag}_c3_$c -o run --output-format csv -- python3 $R/bench.py --traffic none --steps 6 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 3 --profile-steps 0 > /dev/null 2> $O/prof_${tag}_c3_$c.err || exit 1
       done ;;
     pmc_hbm)
       for c in FETCH_SIZE WRITE_SIZE; do
-        timeout -k 10 500 rocprofv3 --pmc $c -d $O/prof_${tag}_hbm_$c -o run --output-format csv -- python3 $R/bench.py --scale 0.1075 --precond jacobi --steps 1 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 0 --profile-steps 0 > /dev/null 2> $O/prof_${tag}_hbm_$c.err || exit 1
+        timeout -k 10 500 rocprofv3 --pmc $c -d $O/prof_${tag}_hbm_$c -o run --output-format csv -- python3 $R/bench.py --traffic none --scale 0.1075 --precond jacobi --steps 1 --warmup 5 --sweep-points 0 --cpu-steps 0 --hbm-scale 0 --jacobi-steps 0 --profile-steps 0 > /dev/null 2> $O/prof_${tag}_hbm_$c.err || exit 1
       done ;;
     amg)
       HEATFLOW_DEBUG=1 timeout -k 10 200 python3 $R/scripts/gpu_probe.py 0.43 8 3 1 > $O/prof_${tag}_amg.log 2>&1 || exit 1

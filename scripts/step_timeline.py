@@ -21,8 +21,8 @@ which = int(sys.argv[2]) if len(sys.argv) > 2 else len(steps) // 2
 i0, i1 = steps[which]
 t0 = int(rows[i0]["Start_Timestamp"])
 prev_end, busy, gaps = t0, 0, 0.0
-hot = {"k_pcg_update_amg", "k_spmv_vec<64, 0, float>", "k_spmv_row<0, float>", "k_dense_mv_f32", "k_spmv<3, true, double>",
-       "k_spmv<0, true, float>", "k_spmv<6, true, float>", "k_spmv<4, true, double>", "k_spmv<9, true, double>"}
+hot = {"k_pcg_update_amg", "k_spmv_vec<64, 0, float>", "k_spmv_row<0, float>", "k_dense_mv_f32", "k_spmv<3, true, double, 8>",
+       "k_spmv<0, true, float, 8>", "k_spmv<0, true, float, 4>", "k_spmv<6, true, float, 4>", "k_spmv<6, true, float, 8>", "k_spmv<4, true, double, 8>", "k_spmv<9, true, double, 8>"}
 for i in range(i0, i1):
     s, e = int(rows[i]["Start_Timestamp"]), int(rows[i]["End_Timestamp"])
     gap = (s - prev_end) / 1e3
