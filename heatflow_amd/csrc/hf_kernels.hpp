@@ -787,7 +787,7 @@ __global__ __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       // !live (no further chunk; q = the current one): every wavefront re-reads the chunk's first 32 entries, results
       // unused.  The offset stays a per-lane value on purpose: with a uniform parked index the compiler turns the loads
       // into scalar ones behind a branch and waits for every load in flight there.
-      const int dl = q.d1 - 1, kl = max(q.k1 - 1, 0);
+      const int dl = max(q.d1 - 1, 0), kl = max(q.k1 - 1, 0);   // a chunk of empty rows has an empty list
       const int t = static_cast<int>(threadIdx.x);
 #pragma unroll
       for (int u = 0; u < HF_STAGE_U; ++u) lhead[u] = comp.dict[min(q.d0 + (live ? t + u * TS : (t & 31)), dl)];
