@@ -7,6 +7,7 @@ Tolerances (float64):
     i.e. ~4e-8 relative; measured ~3e-6 K at the default PCG rtol = 1e-10)
 """
 import os
+import re
 import numpy as np
 import pytest
 
@@ -963,6 +964,52 @@ def test_polled_and_copied_back_loops_give_identical_results(hip, tmp_path):
     for key in ("u", "it", "ub", "bit"):
         assert np.array_equal(out["1"][key], out["0"][key]), key
     assert out["1"]["it"].max() >= 5 and out["1"]["bit"].max() >= 3
+
+
+@pytest.mark.gpu
+def test_chunk_pipeline_of_the_transfer_operators_on_small_and_oversized_chunks(hip, tmp_path):
+    """The LDS-staged kernel runs the single-precision transfer operators with a software pipeline over a workgroup's
+    chunks (next chunk's list head and stream in flight, hf_kernels.hpp).  By default only operators of >= 100 000 rows
+    take it (C3 and larger: test_gpu_fullsize.py); here HEATFLOW_STREAM_MIN_ROWS sends every level of a 50 k-node
+    hierarchy through it, with the default chunk limit (4 or 8 stream entries per lane in flight), with tiny chunks (many
+    per workgroup, ragged ends) and with chunks beyond what the pipeline keeps in registers (entries past 8 per lane
+    and column lists past 1024 entries take the second, unpipelined pass).  Same preconditioner up to the summation
+    order inside a row: fields agree to PCG tolerance, iteration counts to +-1.  One subprocess per setting (the
+    switches are read once)."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(os.path.join(ROOT, 'tests'))!r})\n"
+        "from conftest import build_case\n"
+        "from helpers import make_problem\n"
+        "cfg, stack, mesh = build_case('geballe_with_diamond', 2.0)\n"
+        "prob = make_problem(cfg, stack, mesh, precond=1)\n"
+        "_, _, it = prob.run(14, time_varying=[prob.bcs[3]])\n"
+        "info = prob.backend.amg_info()\n"
+        "np.savez(sys.argv[1], u=prob.state(), it=np.array(it), rows=np.array(info['rows']))\n"
+        "prob.close()\n")
+    settings = {"default": {}, "stream": {"HEATFLOW_STREAM_MIN_ROWS": "300"},
+                "tiny": {"HEATFLOW_STREAM_MIN_ROWS": "300", "HEATFLOW_STREAM_NNZ": "700"},
+                "oversized": {"HEATFLOW_STREAM_MIN_ROWS": "300", "HEATFLOW_STREAM_NNZ": "6500"}}
+    out, staged = {}, {}
+    for name, extra in settings.items():
+        res = subprocess.run([sys.executable, str(script), str(tmp_path / f"{name}.npz")],
+                             env=dict(os.environ, HEATFLOW_DEBUG="1", **extra), capture_output=True, text=True)
+        assert res.returncode == 0, (name, res.stderr[-2000:])
+        out[name] = np.load(tmp_path / f"{name}.npz")
+        # the set-up's operator table ("[amg] level 1 GP ... stream rpc 64 lanes 32 f32 c16"): which operators the kernel runs
+        staged[name] = sorted(set(re.findall(r"\[amg\] level (\d+) (\w+) .* stream rpc (\d+) lanes \d+ f32 c16", res.stdout + res.stderr)))
+    ref = out["default"]
+    assert ref["it"].max() >= 5 and len(ref["rows"]) >= 3
+    assert staged["default"] == [] and len(staged["stream"]) >= 4, staged
+    assert max(int(r) for _, _, r in staged["tiny"]) < max(int(r) for _, _, r in staged["stream"]) <= max(int(r) for _, _, r in staged["oversized"]), staged
+    for name in ("stream", "tiny", "oversized"):
+        assert np.array_equal(out[name]["rows"], ref["rows"]), name
+        assert np.abs(out[name]["it"].astype(int) - ref["it"].astype(int)).max() <= 1, (name, out[name]["it"], ref["it"])
+        assert np.abs(out[name]["u"] - ref["u"]).max() <= 1e-5, (name, np.abs(out[name]["u"] - ref["u"]).max())
 
 
 @pytest.mark.gpu
