@@ -392,7 +392,7 @@ __global__ void k_double_to_float(int64_t n, const double* __restrict__ src, flo
 // double or converted to float, kernel geometry, and - for operators the LDS-staged kernel runs in float - the compressed
 // column stream, built on the device.  `g`'s arrays move into `d` (idx, ptr; val unless converted).
 int adopt_csr(hf_ctx* ctx, GpuScratch& S, GCsr& g, DevCsr& d, bool f32, bool stream = true) {
-  static const int min_rows = std::getenv("HEATFLOW_STREAM_MIN_ROWS") ? std::atoi(std::getenv("HEATFLOW_STREAM_MIN_ROWS")) : 100000;
+  static const int min_rows = std::getenv("HEATFLOW_STREAM_MIN_ROWS") ? std::atoi(std::getenv("HEATFLOW_STREAM_MIN_ROWS")) : 20000;
   static const int max_nnz = std::getenv("HEATFLOW_STREAM_NNZ") ? std::atoi(std::getenv("HEATFLOW_STREAM_NNZ")) : 4096;
   d = DevCsr();
   d.nrow = g.nrow; d.ncol = g.ncol; d.nnz = g.nnz;

@@ -41,7 +41,7 @@ int upload_csr(hf_ctx* ctx, const amg::Csr& h, DevCsr& d, bool f32 = false, bool
   d.nrow = h.nrow; d.ncol = h.ncol; d.nnz = h.nnz(); d.lanes = lanes_for(h);
   for (int i = 0; i < h.nrow; ++i) d.max_row = std::max(d.max_row, h.ptr[i + 1] - h.ptr[i]);
   d.rpc = 0;
-  static const int min_rows = std::getenv("HEATFLOW_STREAM_MIN_ROWS") ? std::atoi(std::getenv("HEATFLOW_STREAM_MIN_ROWS")) : 100000;
+  static const int min_rows = std::getenv("HEATFLOW_STREAM_MIN_ROWS") ? std::atoi(std::getenv("HEATFLOW_STREAM_MIN_ROWS")) : 20000;
   static const int max_nnz = std::getenv("HEATFLOW_STREAM_NNZ") ? std::atoi(std::getenv("HEATFLOW_STREAM_NNZ")) : 4096;
   if (stream && h.nrow >= min_rows) {  // enough 512-row chunks to fill the chip: LDS-staged kernel, chunk products within 64 KB
     for (int rpc = TS; rpc >= 32; rpc /= 2) {

@@ -969,8 +969,8 @@ def test_polled_and_copied_back_loops_give_identical_results(hip, tmp_path):
 @pytest.mark.gpu
 def test_chunk_pipeline_of_the_transfer_operators_on_small_and_oversized_chunks(hip, tmp_path):
     """The LDS-staged kernel runs the single-precision transfer operators with a software pipeline over a workgroup's
-    chunks (next chunk's list head and stream in flight, hf_kernels.hpp).  By default only operators of >= 100 000 rows
-    take it (C3 and larger: test_gpu_fullsize.py); here HEATFLOW_STREAM_MIN_ROWS sends every level of a 50 k-node
+    chunks (next chunk's list head and stream in flight, hf_kernels.hpp).  By default only operators of >= 20 000 rows
+    take it (stock mesh and larger: test_gpu_fullsize.py); here HEATFLOW_STREAM_MIN_ROWS sends every level of a 50 k-node
     hierarchy through it, with the default chunk limit (4 or 8 stream entries per lane in flight), with tiny chunks (many
     per workgroup, ragged ends) and with chunks beyond what the pipeline keeps in registers (entries past 8 per lane
     and column lists past 1024 entries take the second, unpipelined pass).  Same preconditioner up to the summation
@@ -991,7 +991,7 @@ def test_chunk_pipeline_of_the_transfer_operators_on_small_and_oversized_chunks(
         "info = prob.backend.amg_info()\n"
         "np.savez(sys.argv[1], u=prob.state(), it=np.array(it), rows=np.array(info['rows']))\n"
         "prob.close()\n")
-    settings = {"default": {}, "stream": {"HEATFLOW_STREAM_MIN_ROWS": "300"},
+    settings = {"default": {"HEATFLOW_STREAM_MIN_ROWS": "1000000"}, "stream": {"HEATFLOW_STREAM_MIN_ROWS": "300"},
                 "tiny": {"HEATFLOW_STREAM_MIN_ROWS": "300", "HEATFLOW_STREAM_NNZ": "700"},
                 "oversized": {"HEATFLOW_STREAM_MIN_ROWS": "300", "HEATFLOW_STREAM_NNZ": "6500"}}
     out, staged = {}, {}
