@@ -359,11 +359,15 @@ void launch_vec(hf_ctx* c, const DevCsr& m, const double* x, double* y) {
 // residual + R_0 down and P_0 + sweep up, fused down leg Rt_0 with the explicit up leg, or both legs fused; every
 // intermediate level is two launches, the fused down leg Rt and the fused up leg GP (amg_host.hpp), the coarsest level
 // a dense mat-vec.  With `test_convergence` the first kernel of the cycle tests the iterate the cycle starts from.
-void vcycle(hf_ctx* c, int out_slot, bool test_convergence = false) {
+// `part`: the whole cycle, only its first kernel (the one that tests), or everything after it - the polled loop holds the
+// rest of a cycle back while the test it is waiting for may end the solve (pcg_solve).
+enum CyclePart { CYCLE_ALL = 0, CYCLE_FIRST = 1, CYCLE_REST = 2 };
+void vcycle(hf_ctx* c, int out_slot, bool test_convergence = false, CyclePart part = CYCLE_ALL) {
   const int nl = static_cast<int>(c->amg.size());
   DevLevel& L0 = c->amg[0];
   if (nl == 1) {  // no coarse level: one more Jacobi sweep keeps the operator symmetric
-    launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
+    if (part != CYCLE_REST)
+      launch_spmv<4>(c, c->d_A, c->d_z, c->d_z2, c->d_part_rz + out_slot * MAXP, c->d_r, nullptr, nullptr, nullptr, L0.omega);
     return;
   }
   const bool fused0 = L0.GP.nrow > 0;     // both legs of the finest level fused
@@ -373,12 +377,14 @@ void vcycle(hf_ctx* c, int out_slot, bool test_convergence = false) {
   if (L0.Rt.nrow > 0 && (fused0 || !c->amg_fine_stale)) {
     // finest level through its fused legs: b_1 = Rt_0 r (pre-smoothing from zero, residual and restriction in one
     // operator; early exit if the update before it has converged)
-    launch_stream<0>(c, L0.Rt, c->d_r, c->amg[1].b, nullptr, nullptr, test_convergence ? c->d_part_zz : nullptr);
+    if (part != CYCLE_REST) launch_stream<0>(c, L0.Rt, c->d_r, c->amg[1].b, nullptr, nullptr, test_convergence ? c->d_part_zz : nullptr);
   } else {
-    launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r, nullptr, nullptr,   // t = r - A z (+ early exit on convergence)
-                   test_convergence ? c->d_part_zz : nullptr);
-    launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);                              // b_1 = R_0 t
+    if (part != CYCLE_REST)
+      launch_spmv<3>(c, c->d_A, c->d_z, c->d_tmp, nullptr, c->d_r, nullptr, nullptr,   // t = r - A z (+ early exit on convergence)
+                     test_convergence ? c->d_part_zz : nullptr);
+    if (part != CYCLE_FIRST) launch_vec<0>(c, L0.R, c->d_tmp, c->amg[1].b);      // b_1 = R_0 t
   }
+  if (part == CYCLE_FIRST) return;
   for (int l = 1; l + 1 < nl; ++l) launch_vec<0>(c, c->amg[l].Rt, c->amg[l].b, c->amg[l + 1].b);   // b_{l+1} = Rt_l b_l
   {
     DevLevel& Lc = c->amg[nl - 1];
@@ -404,7 +410,8 @@ void vcycle(hf_ctx* c, int out_slot, bool test_convergence = false) {
 }
 
 // One multigrid-PCG iteration: iteration head (as above), update (alpha, x, r, z0 = w D^-1 r), V-cycle (z, r.z)
-void launch_amg_iteration(hf_ctx* c, double* x, int parity) {
+void launch_amg_iteration(hf_ctx* c, double* x, int parity, CyclePart part = CYCLE_ALL) {
+  if (part == CYCLE_REST) { vcycle(c, parity ^ 1, true, CYCLE_REST); return; }
   const bool timed = c->prof && c->prof_used < PROF_PAIRS;
   hipEvent_t e0 = timed ? c->prof_ev[2 * c->prof_used] : nullptr, e1 = timed ? c->prof_ev[2 * c->prof_used + 1] : nullptr;
   launch_spmv<9>(c, c->d_A, c->d_z2, c->d_Ap, c->d_part_pAp, nullptr, c->d_p, c->d_part_rz, c->d_part_zz, 0.0, nullptr, e0,
@@ -413,7 +420,7 @@ void launch_amg_iteration(hf_ctx* c, double* x, int parity) {
   hipLaunchKernelGGL(k_pcg_update_amg, dim3(c->P), dim3(TPB), 0, c->stream, c->n, c->nchunks, c->P, parity, c->d_scal,
                      c->d_part_pAp, c->d_part_rz, c->d_part_zz, x, c->d_r, c->d_p, c->d_Ap, c->d_dinv,
                      c->amg[0].omega, c->amg[0].GP.nrow > 0 ? static_cast<double*>(nullptr) : c->d_z);
-  vcycle(c, parity ^ 1, true);
+  vcycle(c, parity ^ 1, true, part);
 }
 
 // HEATFLOW_POLL=0: bursts + copy-back of the scalars instead of the polled, one-test-ahead loops (A/B and diagnosis)
@@ -526,9 +533,18 @@ int pcg_solve(hf_ctx* ctx, const LinSys& sys, bool use_amg, double rtol, double 
       HF_TRY(wait_tested(ctx, 0));
       if (ctx->h_scal->done == 1) return finish(HF_OK);
     }
+    // After the blind burst the solve is expected to end within an iteration or two.  From there an iteration is queued up
+    // to the kernel that tests (head, update, first kernel of the cycle) and the rest of its cycle only once the test
+    // says "not yet": the device idles for the few microseconds the host needs to see the test and launch, instead of
+    // running the seven remaining launches of a cycle nobody needs (4.6 us each; HEATFLOW_HOLD_BACK=0: whole iterations).
+    static const bool hold_back = !(std::getenv("HEATFLOW_HOLD_BACK") && std::getenv("HEATFLOW_HOLD_BACK")[0] == '0');
     int burst = std::max(1, std::min(max_it, *pred - 2));
+    bool rest_pending = false;      // the last launched iteration stops after its testing kernel
     while (true) {
-      for (int k = 0; k < burst; ++k) launch_amg_iteration(ctx, sys.x, (launched + k) & 1);
+      if (rest_pending) launch_amg_iteration(ctx, sys.x, (launched - 1) & 1, CYCLE_REST);
+      const bool split = hold_back && burst == 1 && launched > 0;
+      for (int k = 0; k < burst; ++k) launch_amg_iteration(ctx, sys.x, (launched + k) & 1, split ? CYCLE_FIRST : CYCLE_ALL);
+      rest_pending = split;
       launched += burst;
       HF_HIP(hipGetLastError());
       const int rc = wait_tested(ctx, launched);
