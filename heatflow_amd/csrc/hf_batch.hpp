@@ -1001,7 +1001,9 @@ struct BatchOps {
     reduce(c, rz_out, B.red->rz[out_slot], B.part_zz, B.red->zz);   // r.z of this cycle and (D^-1 r)^2 of the last update
   }
 
-  static void iteration(hf_ctx* c, bool use_amg, int parity) {
+  // `part` (multigrid only): the whole iteration, up to the reduction that tests and publishes, or the V-cycle after it
+  static void iteration(hf_ctx* c, bool use_amg, int parity, CyclePart part = CYCLE_ALL) {
+    if (part == CYCLE_REST) { vcycle(c, parity ^ 1); return; }
     hf_ctx::Batch& B = c->batch;
     // hf_set_profile: the iteration heads of a solve (its first PROF_PAIRS) carry event pairs, harvested when the solve ends
     const bool timed = c->prof && c->prof_used < PROF_PAIRS;
@@ -1015,7 +1017,7 @@ struct BatchOps {
       // (D^-1 r)^2 of the new iterates: columns that have converged are marked done here, so that the V-cycle below
       // does no work for them (it used to be found out by the next iteration head, one cycle too late)
       reduce(c, B.part_zz, B.red->zz, nullptr, nullptr, B.scal);
-      vcycle(c, parity ^ 1);
+      if (part == CYCLE_ALL) vcycle(c, parity ^ 1);
     } else {
       spmv<9>(c, Avals(c), B.z, B.Ap, B.part_pAp, nullptr, B.p, B.part_rz, B.part_zz, 0.0, parity, e0, e1);
       reduce(c, B.part_pAp, B.red->pAp);
@@ -1119,9 +1121,16 @@ struct BatchOps {
         HF_TRY(wait_tested(ctx, 0, &all_done, &iters, &breakdown));
         if (all_done) return HF_OK;
       }
+      // after the blind burst the V-cycle of an iteration is held back until its test says that a column still needs it
+      // (pcg_solve in hf_solver.hpp; HEATFLOW_HOLD_BACK=0: whole iterations)
+      static const bool hold_back = !(std::getenv("HEATFLOW_HOLD_BACK") && std::getenv("HEATFLOW_HOLD_BACK")[0] == '0');
       int burst = std::max(1, std::min(max_it, B.pred_iters - 2));
+      bool rest_pending = false;
       while (true) {
-        for (int k = 0; k < burst; ++k) iteration(ctx, true, (launched + k) & 1);
+        if (rest_pending) iteration(ctx, true, (launched - 1) & 1, CYCLE_REST);
+        const bool split = hold_back && burst == 1 && launched > 0;
+        for (int k = 0; k < burst; ++k) iteration(ctx, true, (launched + k) & 1, split ? CYCLE_FIRST : CYCLE_ALL);
+        rest_pending = split;
         launched += burst;
         HF_HIP(hipGetLastError());
         HF_TRY(wait_tested(ctx, launched, &all_done, &iters, &breakdown));
