@@ -1182,9 +1182,11 @@ struct BatchOps {
         hipLaunchKernelGGL((kb_lift<NV, OPK>), dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, ctx->nlift_rows, ctx->d_lift_rows,
                            ctx->d_lift_ptr, ctx->d_lift_bc, Liftop(ctx), g_dev, B.b);
       }
-      hipLaunchKernelGGL((kb_set_bc<NV>), dim3((nb * NV + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, g_dev, B.b, B.u);
     }
     const ProjVecs act = proj_active(B);
+    // set_bc once: after the combination when there is one (the basis vectors are zero on the Dirichlet rows)
+    if (nb > 0 && act.m == 0)
+      hipLaunchKernelGGL((kb_set_bc<NV>), dim3((nb * NV + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, g_dev, B.b, B.u);
     if (act.m > 0) {
       hipLaunchKernelGGL((kb_proj_dots<NV>), dim3(B.Pb), dim3(TPB), 0, ctx->stream, ctx->n, act, B.b,
                          B.ppending >= 0 ? B.pF[B.ppending] : static_cast<const double*>(nullptr), B.ppart);

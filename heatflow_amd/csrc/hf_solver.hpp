@@ -762,15 +762,18 @@ int step_device(hf_ctx* ctx, const double* g_host, const double* g_dev, double r
       ctx->have_prev = true;
     }
   }
+  const bool combine = projected && proj_active(ctx).m > 0;
   if (nb > 0) {
     if (ctx->nlift_rows > 0)  // apply_lifting (:477)
       hipLaunchKernelGGL(k_lift, dim3((ctx->nlift_rows + 255) / 256), dim3(256), 0, ctx->stream, ctx->nlift_rows,
                          ctx->d_lift_rows, ctx->d_lift_ptr, ctx->d_lift_bc, ctx->d_lift_val, g, ctx->d_b);
-    // set_bc (:479); the same values seed the iterate
-    hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, g,
-                       ctx->d_b, ctx->d_u);
+    // set_bc (:479); the same values seed the iterate.  With a projected start vector it runs once, after the combination
+    // below: the basis vectors are zero on the Dirichlet rows, so the dot products do not see what b holds there
+    if (!combine)
+      hipLaunchKernelGGL(k_set_bc, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, ctx->d_bc_dofs, g,
+                         ctx->d_b, ctx->d_u);
   }
-  if (projected && proj_active(ctx).m > 0) {
+  if (combine) {
     hf_ctx::Proj& Q = ctx->proj;
     proj_column(ctx, Q.pending, ctx->d_b, true);     // Gram column of the pair stored after the last step + h + alpha
     Q.pending = -1;
