@@ -226,6 +226,20 @@ struct BComp {
   int rpc, nchunks, cap_nnz /* even */, cap_dict;
 };
 
+// measurement builds (-DHF_PHASE_CLOCK=<any> -DHF_PHASE_CLOCK_B=<mode>, PHASE_BATCH_NV=<nv> scripts/phase_clock.py): phase stamps of
+// kb_spmv_lds<mode> as in k_spmv
+#ifndef HF_PHASE_CLOCK_B
+#define HF_PHASE_CLOCK_B -1
+#endif
+#if HF_PHASE_CLOCK_B >= 0 && HF_PHASE_CLOCK >= 0
+#define HFB_STAMP(slot)                                                                                          \
+  do {                                                                                                           \
+    if (MODE == HF_PHASE_CLOCK_B && threadIdx.x == 0 && (slot) < 16) g_phase[blockIdx.x * 16 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define HFB_STAMP(slot) do { } while (0)
+#endif
+
 template <int MODE, int NV, int OPK>
 __global__ __launch_bounds__(KB_BT) void kb_spmv_lds(int n, const int32_t* __restrict__ rowptr, const BOp op,
                                                    const double* __restrict__ x, double* __restrict__ y, Scal* __restrict__ scal,
@@ -265,6 +279,9 @@ __global__ __launch_bounds__(KB_BT) void kb_spmv_lds(int n, const int32_t* __res
   const double dj = OPK == OP_AFFINE ? op.delta[j] : 0.0;
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   const ChunkIter sched(comp.nchunks);
+  HFB_STAMP(0);
+  int stamp_at = 1;
+  (void)stamp_at;
   for (int chunk = sched.chunk; any_active && chunk < sched.end; chunk += sched.step) {
     const int r0 = chunk * comp.rpc, r1 = min(n, r0 + comp.rpc);
     const int k0 = rowptr[r0], nk = rowptr[r1] - k0;
@@ -283,6 +300,7 @@ __global__ __launch_bounds__(KB_BT) void kb_spmv_lds(int n, const int32_t* __res
         if (OPK == OP_AFFINE) sv1[k + KB_BT] = b1;
       }
     }
+    HFB_STAMP(stamp_at); ++stamp_at;      // matrix stream requested and parked (lane 0's share)
     const int nx = nd * NV;
     for (int i = threadIdx.x; i < nx; i += 2 * KB_BT) {
       const bool two = i + KB_BT < nx;
@@ -293,6 +311,7 @@ __global__ __launch_bounds__(KB_BT) void kb_spmv_lds(int n, const int32_t* __res
     }
     const int own = comp.own[chunk];
     __syncthreads();
+    HFB_STAMP(stamp_at); ++stamp_at;      // chunk staged
     // ---- products: thread (row, column), RPP rows per pass
     for (int rb = r0; rb < r1; rb += RPP) {
       const int row = rb + rl;
@@ -342,6 +361,7 @@ __global__ __launch_bounds__(KB_BT) void kb_spmv_lds(int n, const int32_t* __res
       }
     }
     __syncthreads();
+    HFB_STAMP(stamp_at); ++stamp_at;      // rows done
   }
   // the consumers (kb_reduce) add `npart` slots per column: this launch may have fewer workgroups, the rest are zeros
   if (MODE == 2 || MODE == 9 || (MODE == 4 && part0 != nullptr)) {

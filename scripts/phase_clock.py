@@ -20,15 +20,33 @@ def main():
     from heatflow_amd import hip_backend as hb
     from helpers import make_problem
 
+    batch_nv = int(os.environ.get("PHASE_BATCH_NV", "0"))       # > 0: one batch of that many kappa points (kb_spmv_lds stamps)
     cfg, stack, mesh = build_case("geballe_with_diamond", scale)
-    prob = make_problem(cfg, stack, mesh, assembly_mode=0, precond=1)
-    heated = [prob.bcs[3]]
-    prob.run(12, watcher_nodes=None, time_varying=heated)
     lib = hb.load_library()
     buf = np.zeros(1024 * 16, np.uint64)
-    rc = lib.hf_debug_phases(buf.ctypes.data_as(ctypes.c_void_p))
-    assert rc == 0
-    prob.close()
+    if batch_nv > 0:
+        import copy
+        from conftest import HEATING_CSV
+        from heatflow_amd.driver import SimulationSession
+        from heatflow_amd.geometry import build_stack, watcher_points
+        cfg["heating"]["file"] = HEATING_CSV
+        dt0 = float(cfg["timing"]["t_final"]) / int(cfg["timing"]["num_steps"])
+        cfg["timing"]["num_steps"], cfg["timing"]["t_final"] = 12, dt0 * 12
+        cfgs = []
+        for j in range(batch_nv):
+            c = copy.deepcopy(cfg)
+            c["mats"]["p_sample"]["k"] = 3.3 + j / max(batch_nv - 1, 1)
+            cfgs.append(c)
+        sess = SimulationSession(mesh.coords, mesh.tris, mesh.tags, mesh.material_tags)
+        sess.run_batch(cfgs, [build_stack(c) for c in cfgs], watcher_points(cfgs[0]))
+        assert lib.hf_debug_phases(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+        sess.close()
+    else:
+        prob = make_problem(cfg, stack, mesh, assembly_mode=0, precond=1)
+        heated = [prob.bcs[3]]
+        prob.run(12, watcher_nodes=None, time_varying=heated)
+        assert lib.hf_debug_phases(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+        prob.close()
     t = buf.reshape(1024, 16).astype(np.float64) * 0.01      # us
     used = t[:, 0] > 0
     t = t[used]
@@ -39,7 +57,7 @@ def main():
     print(f"== {label}: {used.sum()} workgroups stamped; first entry -> last exit {end.max() - t0:.2f} us; entries spread over "
           f"{t[:, 0].max() - t0:.2f} us (median entry +{np.median(t[:, 0]) - t0:.2f})")
     print(f"   stamps per workgroup: {dict(zip(*np.unique(nst, return_counts=True)))}  (1 + 3 per chunk)")
-    names = ["staged", "products", "rows"]
+    names = ["stream parked", "slice staged", "rows"] if batch_nv > 0 else ["staged", "products", "rows"]
     for c in range(4):
         rows = t[nst >= 1 + 3 * (c + 1)]
         if len(rows) == 0:
