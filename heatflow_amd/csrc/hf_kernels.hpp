@@ -675,10 +675,11 @@ __global__ __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       beta = rz_new / rz_old;
     }
   }
-  if ((MODE == 3 || MODE == 0) && part2 != nullptr) {
-    // first kernel of a V-cycle inside the PCG loop: the update that precedes it left the (D^-1 r)^2 partials of the new
-    // iterate - if that iterate has converged, the cycle (and every later launch of this burst) is skipped here
-    // instead of after the cycle, by the next iteration head
+  // first kernel of a V-cycle inside the PCG loop: the update that precedes it left the (D^-1 r)^2 partials of the new
+  // iterate - if that iterate has converged, the cycle (and every later launch of this burst) is skipped here instead of
+  // after the cycle, by the next iteration head.  True: converged, the caller returns.
+  auto cycle_gate = [&]() {
+    if (!((MODE == 3 || MODE == 0) && part2 != nullptr)) return false;
     double v2 = 0.0;
     for (int k = threadIdx.x; k < npart; k += TS) v2 += part2[k];
     const double zz = block_sum<TS / 64>(v2, s4);
@@ -687,8 +688,10 @@ __global__ __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       if (conv) { scal->zz = zz; scal->done = 1; }
       mirror_publish(scal->mirror, zz, scal->iters, conv ? 1 : 0, scal->epoch);
     }
-    if (conv) return;
-  }
+    return conv;
+  };
+  constexpr bool PIPELINED = C16 && (HF_PIPE == 2 || (HF_PIPE == 1 && sizeof(VT) == 4));
+  if (!PIPELINED && cycle_gate()) return;     // (the pipelined path requests its first chunk before it adds up the partials)
   const ChunkIter sched(nchunks);
   HF_STAMP(0);
   int stamp_at = 1;
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       }
     }
   };
-  if (C16 && (HF_PIPE == 2 || (HF_PIPE == 1 && sizeof(VT) == 4))) {
+  if (PIPELINED) {
     // Software pipeline over the workgroup's chunks.  A chunk needs, in dependent order: its bounds -> the head of its
     // column list and its matrix stream (values, 16-bit positions) -> the gathered operand slice.  While chunk c is
     // worked on, the bounds, the list head and the first UN * TS entries of the stream of chunk c+1 are already in flight
@@ -802,6 +805,7 @@ __global__ __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     double* xd = sprod + comp.xd_off;
     Bounds cur = bounds(min(sched.chunk, nchunks - 1));
     heads(cur, sched.chunk < sched.end);
+    if (cycle_gate()) return;       // the first chunk's requests are out: the test's reduction runs under their latency
     for (int chunk = sched.chunk; chunk < sched.end; chunk += sched.step) {
       const bool more = chunk + sched.step < sched.end;
       const int r0 = chunk * rpc, r1 = min(n, r0 + rpc);
