@@ -956,13 +956,15 @@ def test_polled_and_copied_back_loops_give_identical_results(hip, tmp_path):
         "np.savez(sys.argv[1], u=u, it=np.array(it), ub=ub, bit=np.array(bit))\n"
         "prob.close()\n")
     out = {}
-    for flag in ("1", "0"):
-        env = dict(os.environ, HEATFLOW_POLL=flag)
-        res = subprocess.run([sys.executable, str(script), str(tmp_path / f"o{flag}.npz")], env=env, capture_output=True, text=True)
+    # "whole": polled, but whole iterations queued to the end (HEATFLOW_HOLD_BACK=0) instead of the last cycles held back until
+    # their test asks for them - the launches that differ are the ones that return at their first instruction
+    for flag, extra in (("1", {"HEATFLOW_POLL": "1"}), ("0", {"HEATFLOW_POLL": "0"}), ("whole", {"HEATFLOW_POLL": "1", "HEATFLOW_HOLD_BACK": "0"})):
+        res = subprocess.run([sys.executable, str(script), str(tmp_path / f"o{flag}.npz")], env=dict(os.environ, **extra), capture_output=True, text=True)
         assert res.returncode == 0, res.stderr[-2000:]
         out[flag] = np.load(tmp_path / f"o{flag}.npz")
     for key in ("u", "it", "ub", "bit"):
         assert np.array_equal(out["1"][key], out["0"][key]), key
+        assert np.array_equal(out["1"][key], out["whole"][key]), key
     assert out["1"]["it"].max() >= 5 and out["1"]["bit"].max() >= 3
 
 
