@@ -55,3 +55,33 @@ def test_cpu_farm_worker_reports_a_pool_of_single_threaded_processes():
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["kind"] == "port" and out["cores"] == 2 and out["points"] == 2 and out["unit"] == "DOF-updates/s"
     assert out["value"] > 0 and out["wall_s"] >= out["per_point_s_mean"] * 0.5
+
+
+def test_side_guard_writes_the_headline_and_ends_the_process_when_a_side_measurement_hangs(tmp_path):
+    """N > 1: a collective of the C5 side measurement that never completes must not take the measured headline with it.  The
+    guard (bench.SideGuard) writes the line with the failure noted in the side measurement's place and exits 0; disarmed in
+    time it does nothing."""
+    script = tmp_path / "guard.py"
+    script.write_text(
+        "import json, os, sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "out = {'metric': 'm', 'value': 1.0, 'config': {}}\n"
+        "emit = lambda o: os.write(1, (json.dumps(o) + '\\n').encode())\n"
+        "mode = sys.argv[1]\n"
+        "g = bench.SideGuard(out, emit, 0.2 if mode == 'hang' else 30.0)\n"
+        "if mode == 'hang':\n"
+        "    time.sleep(20)\n"                      # the stuck collective
+        "    sys.exit(3)\n"                         # never reached
+        "assert g.disarm() and not g.disarm()\n"
+        "out['config']['sweep64'] = {'value': 2.0}\n"
+        "emit(out)\n")
+    hang = subprocess.run([sys.executable, str(script), "hang"], capture_output=True, text=True, timeout=60)
+    assert hang.returncode == 0, hang.stderr[-1000:]
+    lines = [ln for ln in hang.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] == 1.0 and "not finished" in line["config"]["sweep64"]["error"] and line["cpu_baseline"] is None
+    ok = subprocess.run([sys.executable, str(script), "ok"], capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0, ok.stderr[-1000:]
+    assert json.loads(ok.stdout.strip())["config"]["sweep64"] == {"value": 2.0}
