@@ -38,6 +38,12 @@ constexpr int NCOL = 32;       // max colours per row block (uint32 mask)
 #endif
 constexpr int MAXP = 1024;     // max workgroups per launch = partial-sum slots per array
 constexpr int MAXRESP = 4;     // boundary-response directions kept per operator
+// projection start vector (k_proj_* in hf_kernels.hpp): solutions kept in the ring, + boundary responses = vectors in all
+#ifndef HF_PROJ_MH
+#define HF_PROJ_MH 6
+#endif
+constexpr int PROJ_MH = HF_PROJ_MH;
+constexpr int PROJ_MT = PROJ_MH + MAXRESP;
 constexpr int TS = 512;        // SpMV workgroup: 512 threads = 8 wavefronts own 512 consecutive rows per chunk
 // rows per chunk of the fine operator's LDS-staged SpMV (a workgroup of TS threads, one row per lane in the row phase;
 // fewer rows than TS: more, shorter chunks per workgroup for the chunk pipeline) and its stream entries per lane in flight
@@ -165,8 +171,8 @@ struct hf_ctx {
   long long resp_solves = 0;
   // hf_set_start_vector kind 3: Galerkin projection on the last solutions and the boundary responses (k_proj_*)
   struct Proj {
-    double *V[10] = {nullptr}, *F[10] = {nullptr};   // slots 0..5: ring of (solution with zeroed Dirichlet entries, its right-hand side); 6..9: responses
-    bool used[10] = {false};
+    double *V[PROJ_MT] = {nullptr}, *F[PROJ_MT] = {nullptr};   // slots 0..PROJ_MH-1: ring of (solution with zeroed Dirichlet entries, its right-hand side); then the responses
+    bool used[PROJ_MT] = {false};
     int next = 0, pending = -1;   // ring slot to overwrite next; slot whose Gram column is still to be computed
     double *G = nullptr, *alpha = nullptr, *part = nullptr;
     bool ready = false;
@@ -245,8 +251,8 @@ struct hf_ctx {
     int Pb = 0, pred_iters = 0;
     bool have_prev = false;
     // projection start vector per column: ring of (solutions with zeroed Dirichlet entries, right-hand sides)
-    double *pV[6] = {nullptr}, *pF[6] = {nullptr}, *pG = nullptr, *palpha = nullptr, *ppart = nullptr;
-    bool pused[6] = {false};
+    double *pV[PROJ_MH] = {nullptr}, *pF[PROJ_MH] = {nullptr}, *pG = nullptr, *palpha = nullptr, *ppart = nullptr;
+    bool pused[PROJ_MH] = {false};
     int pnext = 0, ppending = -1;
     unsigned loaded = 0;         // bit j: column j's operator has been loaded (percol)
     bool lds = false;            // fine-pattern products through kb_spmv_lds (the context's `bcols` tables are for this nv)

@@ -1137,11 +1137,7 @@ __global__ __launch_bounds__(TPB) void k_start_vector(int n, const double* __res
 // A-norm: G alpha = h with G_kl = V_k . F_l, h_k = V_k . f.  V_k holds u^k with its Dirichlet entries zeroed (so
 // every dot product runs over the free rows only), F_k the right-hand side b^k as it was.
 // ------------------------------------------------------------------------------------------
-#ifndef HF_PROJ_MH
-#define HF_PROJ_MH 6
-#endif
-constexpr int PROJ_MH = HF_PROJ_MH;         // solutions kept (macro: A/B builds)
-constexpr int PROJ_MT = PROJ_MH + MAXRESP;  // + boundary responses
+// (PROJ_MH solutions kept + MAXRESP boundary responses = PROJ_MT vectors: hf_context.hpp; HF_PROJ_MH for A/B builds)
 struct ProjVecs { const double* V[PROJ_MT]; int slot[PROJ_MT]; int m; };
 
 // partial sums of h_k = V_k . f and (Fnew != null) of the Gram column g_k = V_k . Fnew, one pass over all vectors
@@ -1196,6 +1192,7 @@ __global__ __launch_bounds__(TPB) void k_proj_dots(int n, ProjVecs a, const doub
 // positive semi-definite, so its largest remaining entry sits on the diagonal); directions whose pivot falls below
 // 1e-12 of the first are left out (nearly dependent solutions).  alpha[slot] receives the coefficients (0 for
 // slots left out), alpha[PROJ_MT] the rank.
+static_assert(PROJ_MT * PROJ_MT <= 1024, "k_proj_solve holds one matrix entry per thread");
 constexpr int PROJ_SOLVE_T = 1024;   // 16 wavefronts: one or two partial arrays each (the sums are the long part of the kernel)
 __global__ __launch_bounds__(PROJ_SOLVE_T) void k_proj_solve(int P, ProjVecs a, int jnew, int do_solve, double* __restrict__ part,
                                                     double* __restrict__ G /* [PROJ_MT][PROJ_MT] by slot */, double* __restrict__ alpha) {
