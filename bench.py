@@ -888,6 +888,23 @@ def main(argv=None):
                                      "what": "16-byte-load read of the operator's values + column indices on this box",
                                      "frac_of_it": achieved / stream_gbs},
             "assembly": asm_roof, "hbm_resident": None}
+        if precond == 1:
+            # the whole multigrid-PCG iteration (iteration head, update, V-cycle: 10 launches at C3): HBM bytes = the per-launch PMC
+            # means kept under profiles/ (scripts/pmc_summary.py; only quoted for exactly this matrix), over the time the loop
+            # spends per iteration - right-hand side, start vector, first residual and the extra cycle of every step included
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
+                    pmc_it = json.load(f)
+                if pmc_it["n"] == n and pmc_it["nnz"] == nnz and pmc_it.get("multigrid_iteration"):
+                    it_bytes = float(pmc_it["multigrid_iteration"]["bytes"])
+                    it_us = 1e3 * (1e3 * elapsed / args.steps) / max(float(np.mean(iters)), 1.0)
+                    out["roofline"]["multigrid_pcg_iteration"] = {
+                        "bytes": it_bytes, "bytes_source": "profiles/pmc_traffic_latest.json (rocprofv3 --pmc passes of scripts/profile_round.sh, same matrix): mean HBM bytes per launch, summed over the launches of one iteration",
+                        "us_per_iteration_in_loop": it_us, "achieved": it_bytes / (it_us * 1e-6) / 1e9,
+                        "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "note": "time per iteration = time per step / iterations per step: includes the step's right-hand side, start vector, first residual and first cycle; the launches of one iteration alone take 119-122 us under rocprofv3 (profiles/r03_c3_iteration_breakdown.txt)"}
+            except (OSError, KeyError, ValueError):
+                pass
         if jacobi is not None:
             # the whole Jacobi-PCG iteration = iteration head + update, 12*nnz + 84*n bytes, over the time the
             # loop really spends per iteration (steps incl. right-hand side and start vector / iterations)

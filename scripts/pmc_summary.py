@@ -44,5 +44,28 @@ with open(out + ".csv", "w") as f:
         f.write(f"{k},{len(fv)},{fk:.0f},{wk:.0f},{corr:.0f},{a if a else ''},{(corr / a if a else float('nan')):.3f}\n")
         if a:
             kern[k] = {"hbm_bytes": corr, "algorithmic": a}
-json.dump({"n": n, "nnz": nnz, "note": __doc__.split("bytes =")[1].strip(), "kernels": kern}, open(out + ".json", "w"), indent=1)
+# one multigrid-PCG iteration = the launches of scripts/iter_breakdown.py's sequence; kernels that appear twice per iteration (the
+# sub-wave kernel: down leg of level 1, up leg of level 2) enter with the mean over their launches, times two.  Launches that
+# returned at their first instruction (after convergence) carry next to nothing and are left out of the means.
+def mean_bytes(k):
+    fv, wv = res["fetch"].get(k, []), res["write"].get(k, [])
+    if not fv:
+        return None
+    f_ok = [v for v in fv if v > 0.1 * max(fv)]
+    w_ok = [v for v in wv if v > 0.1 * max(wv)] if wv and max(wv) > 0 else [0.0]
+    return (2 * statistics.mean(f_ok) + statistics.mean(w_ok)) * 1024
+
+
+iteration = {}
+for k in sorted(res["fetch"]):
+    per_iter = 2 if k.startswith("k_spmv_vec") else 1
+    if k in ("k_spmv<9>", "k_spmv<4>", "k_pcg_update_amg", "k_dense_mv_f32") or k.startswith(("k_spmv<0,f32", "k_spmv<6,f32", "k_spmv<7,f32", "k_spmv_vec<", "k_spmv_row<")):
+        b = mean_bytes(k)
+        if b:
+            iteration[k] = {"bytes_per_launch_mean": b, "launches_per_iteration": per_iter}
+it_total = sum(v["bytes_per_launch_mean"] * v["launches_per_iteration"] for v in iteration.values())
+json.dump({"n": n, "nnz": nnz, "note": __doc__.split("bytes =")[1].strip(), "kernels": kern,
+           "multigrid_iteration": {"bytes": it_total, "kernels": iteration,
+                                   "note": "sum over the launches of one multigrid-PCG iteration (iteration head, update, V-cycle), mean HBM bytes per launch"}},
+          open(out + ".json", "w"), indent=1)
 print(open(out + ".csv").read())
