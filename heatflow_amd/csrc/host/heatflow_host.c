@@ -289,3 +289,278 @@ int64_t hfh_quadtree_leaves(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t
   }
   return cnt;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Nodes and triangles of the mesh from the quadtree's leaves (the second half of Mesh.build_mesh; its numpy
+ * statement stays in heatflow_amd/mesh.py and the tests compare the two bit for bit).
+ *
+ * Node lattice: (nzp + 1) x (nrp + 1) points, key = i * (nrp + 1) + j.  Two bitmaps over it - corners of leaves, and
+ * corners + centres of the leaves that fan - replace the sorted key arrays of the numpy path: "is this edge midpoint a
+ * node" is a bit test, and a node's number is perm[rank of its bit], with the rank from a per-word prefix count.  Nodes
+ * are numbered by the Morton code of (i, j), triangles are listed leaf by leaf in the Morton order of the leaf centres
+ * (both codes from the low 16 bits, as in the numpy path: callers take that path for lattices beyond 65535).
+ * ------------------------------------------------------------------------------------------------ */
+struct hfh_mesh {
+  int64_t n_nodes, n_tris, n_fan;
+  double* coords;      /* n_nodes x 2 */
+  int64_t* node_ij;    /* n_nodes x 2 */
+  int32_t* tris;       /* n_tris x 3 */
+  int32_t* tags;       /* n_tris */
+};
+
+static inline uint32_t spread16(uint32_t v) {
+  v &= 0xFFFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+static inline uint32_t morton16(int64_t i, int64_t j) { return spread16((uint32_t)i) | (spread16((uint32_t)j) << 1); }
+
+/* stable LSD radix sort of (code, payload) pairs by the 32-bit code, three passes of 11 bits; result in (code, pay) */
+static int radix_sort_u32(int64_t n, uint32_t* code, int32_t* pay) {
+  uint32_t* c2 = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
+  int32_t* p2 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  size_t* cnt = (size_t*)malloc(sizeof(size_t) * 2048);
+  if (!c2 || !p2 || !cnt) { free(c2); free(p2); free(cnt); return -ENOMEM; }
+  uint32_t *ca = code, *cb = c2;
+  int32_t *pa = pay, *pb = p2;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int sh = 11 * pass;
+    memset(cnt, 0, sizeof(size_t) * 2048);
+    for (int64_t k = 0; k < n; ++k) ++cnt[(ca[k] >> sh) & 2047u];
+    size_t at = 0;
+    for (int b = 0; b < 2048; ++b) { const size_t c = cnt[b]; cnt[b] = at; at += c; }
+    for (int64_t k = 0; k < n; ++k) { const size_t d = cnt[(ca[k] >> sh) & 2047u]++; cb[d] = ca[k]; pb[d] = pa[k]; }
+    uint32_t* tc = ca; ca = cb; cb = tc;
+    int32_t* tp = pa; pa = pb; pb = tp;
+  }
+  /* three passes: the result sits in the scratch arrays */
+  memcpy(code, ca, sizeof(uint32_t) * (size_t)n);
+  memcpy(pay, pa, sizeof(int32_t) * (size_t)n);
+  free(c2); free(p2); free(cnt);
+  return 0;
+}
+
+typedef struct {
+  int64_t nleaf;
+  const int64_t *i0, *j0, *lev;
+  int64_t stride;
+  uint64_t *corner, *node;
+  uint8_t* flags;          /* bit 0..3: hanging node on the bottom / z1 / top / z0 edge */
+  int32_t* ntri;
+  /* numbering */
+  const uint32_t* rank;    /* set bits of `node` before each word */
+  const int32_t* perm;     /* row-major rank -> node number */
+  /* output */
+  const int32_t* lorder;   /* position -> leaf */
+  const int64_t* toff;     /* position -> first triangle */
+  const int8_t* mat;
+  int32_t nrp;
+  const double* coords;
+  int32_t* tris;
+  int32_t* tags;
+  int degenerate;
+} mesh_arg;
+
+static inline void bit_set(uint64_t* b, int64_t k) { __atomic_fetch_or(&b[k >> 6], (uint64_t)1 << (k & 63), __ATOMIC_RELAXED); }
+static inline int bit_get(const uint64_t* b, int64_t k) { return (int)((b[k >> 6] >> (k & 63)) & 1u); }
+
+static void mesh_corner_rows(int32_t a, int32_t b, void* p) {
+  mesh_arg* m = (mesh_arg*)p;
+  for (int64_t q = a; q < b; ++q) {
+    const int64_t i0 = m->i0[q], j0 = m->j0[q], sz = (int64_t)1 << m->lev[q];
+    bit_set(m->corner, i0 * m->stride + j0);
+    bit_set(m->corner, (i0 + sz) * m->stride + j0);
+    bit_set(m->corner, (i0 + sz) * m->stride + j0 + sz);
+    bit_set(m->corner, i0 * m->stride + j0 + sz);
+  }
+}
+
+static void mesh_flag_rows(int32_t a, int32_t b, void* p) {
+  mesh_arg* m = (mesh_arg*)p;
+  for (int64_t q = a; q < b; ++q) {
+    uint8_t f = 0;
+    if (m->lev[q] >= 1) {
+      const int64_t i0 = m->i0[q], j0 = m->j0[q], sz = (int64_t)1 << m->lev[q], h = sz >> 1;
+      f = (uint8_t)(bit_get(m->corner, (i0 + h) * m->stride + j0) | (bit_get(m->corner, (i0 + sz) * m->stride + j0 + h) << 1) |
+                    (bit_get(m->corner, (i0 + h) * m->stride + j0 + sz) << 2) | (bit_get(m->corner, i0 * m->stride + j0 + h) << 3));
+      if (f) bit_set(m->node, (i0 + h) * m->stride + j0 + h);      /* the fan's centre node */
+    }
+    m->flags[q] = f;
+    m->ntri[q] = f ? 4 + (f & 1) + ((f >> 1) & 1) + ((f >> 2) & 1) + ((f >> 3) & 1) : 2;
+  }
+}
+
+static inline int32_t node_id(const mesh_arg* m, int64_t key) {
+  const uint64_t w = m->node[key >> 6];
+  return m->perm[m->rank[key >> 6] + (uint32_t)__builtin_popcountll(w & (((uint64_t)1 << (key & 63)) - 1))];
+}
+
+static inline void put_tri(mesh_arg* m, int64_t t, int32_t a, int32_t b, int32_t c, int32_t tag) {
+  const double* pa = m->coords + 2 * (size_t)a;
+  const double* pb = m->coords + 2 * (size_t)b;
+  const double* pc = m->coords + 2 * (size_t)c;
+  const double area2 = (pb[0] - pa[0]) * (pc[1] - pa[1]) - (pc[0] - pa[0]) * (pb[1] - pa[1]);
+  if (area2 == 0.0) m->degenerate = 1;
+  int32_t* o = m->tris + 3 * (size_t)t;
+  o[0] = a;
+  if (area2 < 0.0) { o[1] = c; o[2] = b; } else { o[1] = b; o[2] = c; }     /* counter-clockwise in the (z, r) plane */
+  m->tags[t] = tag;
+}
+
+static void mesh_tri_rows(int32_t a, int32_t b, void* p) {
+  mesh_arg* m = (mesh_arg*)p;
+  for (int64_t pos = a; pos < b; ++pos) {
+    const int64_t q = m->lorder[pos];
+    const int64_t i0 = m->i0[q], j0 = m->j0[q], sz = (int64_t)1 << m->lev[q], h = sz >> 1, i1 = i0 + sz, j1 = j0 + sz;
+    const int32_t tag = (int32_t)m->mat[(size_t)i0 * m->nrp + j0] + 1;
+    const int32_t c00 = node_id(m, i0 * m->stride + j0), c10 = node_id(m, i1 * m->stride + j0);
+    const int32_t c11 = node_id(m, i1 * m->stride + j1), c01 = node_id(m, i0 * m->stride + j1);
+    int64_t t = m->toff[pos];
+    const uint8_t f = m->flags[q];
+    if (!f) {                                   /* two right triangles sharing the (c00, c11) diagonal */
+      put_tri(m, t, c00, c10, c11, tag);
+      put_tri(m, t + 1, c00, c11, c01, tag);
+      continue;
+    }
+    const int32_t cc = node_id(m, (i0 + h) * m->stride + j0 + h);
+    const int32_t ea[4] = {c00, c10, c11, c01}, eb[4] = {c10, c11, c01, c00};
+    const int64_t mk[4] = {(i0 + h) * m->stride + j0, i1 * m->stride + j0 + h, (i0 + h) * m->stride + j1, i0 * m->stride + j0 + h};
+    for (int s = 0; s < 4; ++s) {
+      if ((f >> s) & 1) {
+        const int32_t mid = node_id(m, mk[s]);
+        put_tri(m, t++, ea[s], mid, cc, tag);
+        put_tri(m, t++, mid, eb[s], cc, tag);
+      } else {
+        put_tri(m, t++, ea[s], eb[s], cc, tag);
+      }
+    }
+  }
+}
+
+void hfh_mesh_free(hfh_mesh* h) {
+  if (!h) return;
+  free(h->coords); free(h->node_ij); free(h->tris); free(h->tags);
+  free(h);
+}
+
+int hfh_mesh_build(int64_t nleaf, const int64_t* i0, const int64_t* j0, const int64_t* lev, int32_t nzp, int32_t nrp,
+                   const int8_t* mat, int32_t nz, int32_t nr, const double* zc, const double* rc, hfh_mesh** out) {
+  if (!out) return -EINVAL;
+  *out = NULL;
+  if (nleaf <= 0 || nleaf > 0x7fffffffLL / 8 || !i0 || !j0 || !lev || !mat || !zc || !rc || nzp <= 0 || nrp <= 0 || nzp > 65535 ||
+      nrp > 65535 || nz <= 0 || nr <= 0 || nz > nzp || nr > nrp)
+    return -EINVAL;
+  for (int64_t q = 0; q < nleaf; ++q) {
+    const int64_t sz = lev[q] >= 0 && lev[q] <= 30 ? (int64_t)1 << lev[q] : -1;
+    if (sz < 0 || i0[q] < 0 || j0[q] < 0 || i0[q] + sz > nzp || j0[q] + sz > nrp) return -EINVAL;
+  }
+  const int64_t stride = (int64_t)nrp + 1, nkeys = ((int64_t)nzp + 1) * stride;
+  const size_t nwords = (size_t)((nkeys + 63) >> 6);
+  int rc_ = -ENOMEM;
+  hfh_mesh* h = (hfh_mesh*)calloc(1, sizeof(hfh_mesh));
+  uint64_t* corner = (uint64_t*)calloc(nwords, sizeof(uint64_t));
+  uint64_t* node = (uint64_t*)malloc(nwords * sizeof(uint64_t));
+  uint32_t* rank = (uint32_t*)malloc((nwords + 1) * sizeof(uint32_t));
+  uint8_t* flags = (uint8_t*)malloc((size_t)nleaf);
+  int32_t* ntri = (int32_t*)malloc(sizeof(int32_t) * (size_t)nleaf);
+  uint32_t *ncode = NULL, *lcode = NULL;
+  int32_t *npay = NULL, *perm = NULL, *lorder = NULL;
+  int64_t* toff = NULL;
+  mesh_arg m;
+  memset(&m, 0, sizeof m);
+  if (!h || !corner || !node || !rank || !flags || !ntri) goto done;
+  m.nleaf = nleaf; m.i0 = i0; m.j0 = j0; m.lev = lev; m.stride = stride; m.corner = corner; m.node = node; m.flags = flags; m.ntri = ntri;
+  m.mat = mat; m.nrp = nrp;
+  const size_t big = (size_t)1 << 22;      /* par_rows: enough work to pay for threads */
+  par_rows((int32_t)nleaf, nleaf >= 200000 ? big : 0, mesh_corner_rows, &m);
+  memcpy(node, corner, nwords * sizeof(uint64_t));
+  par_rows((int32_t)nleaf, nleaf >= 200000 ? big : 0, mesh_flag_rows, &m);
+  /* ranks of the node bits (row-major), then the nodes in Morton order */
+  int64_t nn = 0;
+  for (size_t w = 0; w < nwords; ++w) { rank[w] = (uint32_t)nn; nn += __builtin_popcountll(node[w]); }
+  rank[nwords] = (uint32_t)nn;
+  if (nn > 0x7fffffffLL) { rc_ = -EOVERFLOW; goto done; }
+  ncode = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)nn);
+  npay = (int32_t*)malloc(sizeof(int32_t) * (size_t)nn);
+  perm = (int32_t*)malloc(sizeof(int32_t) * (size_t)nn);
+  h->coords = (double*)malloc(sizeof(double) * 2 * (size_t)nn);
+  h->node_ij = (int64_t*)malloc(sizeof(int64_t) * 2 * (size_t)nn);
+  if (!ncode || !npay || !perm || !h->coords || !h->node_ij) goto done;
+  {
+    int64_t r = 0;
+    for (size_t w = 0; w < nwords; ++w) {
+      uint64_t bits = node[w];
+      while (bits) {
+        const int64_t key = (int64_t)(w << 6) + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        ncode[r] = morton16(key / stride, key % stride);
+        npay[r] = (int32_t)r;
+        ++r;
+      }
+    }
+  }
+  if ((rc_ = radix_sort_u32(nn, ncode, npay)) != 0) goto done;
+  for (int64_t id = 0; id < nn; ++id) perm[npay[id]] = (int32_t)id;
+  {
+    int64_t r = 0;
+    for (size_t w = 0; w < nwords; ++w) {
+      uint64_t bits = node[w];
+      while (bits) {
+        const int64_t key = (int64_t)(w << 6) + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const int64_t ki = key / stride, kj = key % stride;
+        const int32_t id = perm[r++];
+        h->coords[2 * (size_t)id] = zc[ki < nz ? ki : nz];
+        h->coords[2 * (size_t)id + 1] = rc[kj < nr ? kj : nr];
+        h->node_ij[2 * (size_t)id] = ki;
+        h->node_ij[2 * (size_t)id + 1] = kj;
+      }
+    }
+  }
+  /* leaves in the Morton order of their centres, triangle offsets */
+  lcode = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)nleaf);
+  lorder = (int32_t*)malloc(sizeof(int32_t) * (size_t)nleaf);
+  toff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)nleaf + 1));
+  if (!lcode || !lorder || !toff) { rc_ = -ENOMEM; goto done; }
+  for (int64_t q = 0; q < nleaf; ++q) {
+    const int64_t hh = ((int64_t)1 << lev[q]) >> 1;
+    lcode[q] = morton16(i0[q] + hh, j0[q] + hh);
+    lorder[q] = (int32_t)q;
+  }
+  if ((rc_ = radix_sort_u32(nleaf, lcode, lorder)) != 0) goto done;
+  int64_t nt = 0, nfan = 0;
+  for (int64_t pos = 0; pos < nleaf; ++pos) { toff[pos] = nt; nt += ntri[lorder[pos]]; nfan += flags[lorder[pos]] != 0; }
+  toff[nleaf] = nt;
+  if (nt > 0x7fffffffLL / 3) { rc_ = -EOVERFLOW; goto done; }
+  h->tris = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)nt);
+  h->tags = (int32_t*)malloc(sizeof(int32_t) * (size_t)nt);
+  if (!h->tris || !h->tags) { rc_ = -ENOMEM; goto done; }
+  m.rank = rank; m.perm = perm; m.lorder = lorder; m.toff = toff; m.coords = h->coords; m.tris = h->tris; m.tags = h->tags;
+  par_rows((int32_t)nleaf, nleaf >= 200000 ? big : 0, mesh_tri_rows, &m);
+  if (m.degenerate) { rc_ = -EDOM; goto done; }
+  h->n_nodes = nn; h->n_tris = nt; h->n_fan = nfan;
+  rc_ = 0;
+done:
+  free(corner); free(node); free(rank); free(flags); free(ntri); free(ncode); free(npay); free(perm); free(lcode); free(lorder); free(toff);
+  if (rc_ != 0) { hfh_mesh_free(h); return rc_; }
+  *out = h;
+  return 0;
+}
+
+int hfh_mesh_sizes(const hfh_mesh* h, int64_t* n_nodes, int64_t* n_tris, int64_t* n_fan) {
+  if (!h || !n_nodes || !n_tris || !n_fan) return -EINVAL;
+  *n_nodes = h->n_nodes; *n_tris = h->n_tris; *n_fan = h->n_fan;
+  return 0;
+}
+
+int hfh_mesh_fetch(const hfh_mesh* h, double* coords, int64_t* node_ij, int32_t* tris, int32_t* tags) {
+  if (!h || !coords || !node_ij || !tris || !tags) return -EINVAL;
+  memcpy(coords, h->coords, sizeof(double) * 2 * (size_t)h->n_nodes);
+  memcpy(node_ij, h->node_ij, sizeof(int64_t) * 2 * (size_t)h->n_nodes);
+  memcpy(tris, h->tris, sizeof(int32_t) * 3 * (size_t)h->n_tris);
+  memcpy(tags, h->tags, sizeof(int32_t) * (size_t)h->n_tris);
+  return 0;
+}

@@ -11,7 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libheatflow_host.so")
-EXPORTS = ["hfh_version", "hfh_write_msh22", "hfh_quadtree_levels", "hfh_quadtree_leaves"]
+EXPORTS = ["hfh_version", "hfh_write_msh22", "hfh_quadtree_levels", "hfh_quadtree_leaves", "hfh_mesh_build", "hfh_mesh_sizes",
+           "hfh_mesh_fetch", "hfh_mesh_free"]
 
 _lib = None
 _failed = False
@@ -50,6 +51,15 @@ def load_library():
     lib.hfh_quadtree_levels.argtypes = [i32, i32, i32, p8, p8, p8]
     lib.hfh_quadtree_leaves.restype = C.c_int64
     lib.hfh_quadtree_leaves.argtypes = [i32, i32, i32, p8, C.c_int64, p64, p64, p64]
+    pd = C.POINTER(C.c_double)
+    lib.hfh_mesh_build.restype = C.c_int
+    lib.hfh_mesh_build.argtypes = [C.c_int64, p64, p64, p64, i32, i32, p8, i32, i32, pd, pd, C.POINTER(C.c_void_p)]
+    lib.hfh_mesh_sizes.restype = C.c_int
+    lib.hfh_mesh_sizes.argtypes = [C.c_void_p, p64, p64, p64]
+    lib.hfh_mesh_fetch.restype = C.c_int
+    lib.hfh_mesh_fetch.argtypes = [C.c_void_p, pd, p64, C.POINTER(i32), C.POINTER(i32)]
+    lib.hfh_mesh_free.restype = None
+    lib.hfh_mesh_free.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 
@@ -106,3 +116,36 @@ def quadtree_leaves(level, lmax):
     lib.hfh_quadtree_leaves(level.shape[0], level.shape[1], int(lmax), level.ctypes.data_as(p8), n, i0.ctypes.data_as(p64),
                             j0.ctypes.data_as(p64), lev.ctypes.data_as(p64))
     return i0, j0, lev
+
+
+MESH_LATTICE_MAX = 65535      # Morton codes of the node / leaf order take the low 16 bits of a lattice index
+
+
+def mesh_from_leaves(i0, j0, lev, mat, zc, rc):
+    """Nodes and triangles from the quadtree's leaves (heatflow_host.h: hfh_mesh_build): returns
+    (coords (n, 2) f64, node_ij (n, 2) i64, tris (nt, 3) i32 counter-clockwise, tags (nt,) i32 = material index + 1, n_fan),
+    nodes and triangles in Morton order - bit for bit what the numpy statement in Mesh.build_mesh gives."""
+    lib = load_library()
+    if lib is None:
+        raise RuntimeError("libheatflow_host.so is not available")
+    i0, j0, lev = (np.ascontiguousarray(a, dtype=np.int64) for a in (i0, j0, lev))
+    mat = np.ascontiguousarray(mat, dtype=np.int8)
+    zc, rc = np.ascontiguousarray(zc, dtype=np.float64), np.ascontiguousarray(rc, dtype=np.float64)
+    p8, p64, pd, p32 = C.POINTER(C.c_int8), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    h = C.c_void_p()
+    rc_ = lib.hfh_mesh_build(len(i0), i0.ctypes.data_as(p64), j0.ctypes.data_as(p64), lev.ctypes.data_as(p64), mat.shape[0],
+                             mat.shape[1], mat.ctypes.data_as(p8), len(zc) - 1, len(rc) - 1, zc.ctypes.data_as(pd),
+                             rc.ctypes.data_as(pd), C.byref(h))
+    if rc_ != 0:
+        raise RuntimeError(f"hfh_mesh_build failed ({os.strerror(-rc_)})")
+    try:
+        nn, nt, nf = C.c_int64(), C.c_int64(), C.c_int64()
+        lib.hfh_mesh_sizes(h, C.byref(nn), C.byref(nt), C.byref(nf))
+        coords = np.empty((nn.value, 2), dtype=np.float64)
+        node_ij = np.empty((nn.value, 2), dtype=np.int64)
+        tris = np.empty((nt.value, 3), dtype=np.int32)
+        tags = np.empty(nt.value, dtype=np.int32)
+        lib.hfh_mesh_fetch(h, coords.ctypes.data_as(pd), node_ij.ctypes.data_as(p64), tris.ctypes.data_as(p32), tags.ctypes.data_as(p32))
+    finally:
+        lib.hfh_mesh_free(h)
+    return coords, node_ij, tris, tags, int(nf.value)

@@ -283,6 +283,15 @@ class Mesh:
             i0, j0, lev = hostlib.quadtree_leaves(hostlib.quadtree_levels(mat, allowed, lmax), lmax)
         else:
             i0, j0, lev = self._quadtree_numpy(mat, allowed, lmax, nzp, nrp)
+        if use_native and max(nzp, nrp) <= hostlib.MESH_LATTICE_MAX:
+            # nodes, hanging-node fans, triangles, Morton numbering: native too (heatflow_host.h); the numpy statement below
+            # gives the same arrays bit for bit (tests/test_mesh_geometry.py) and serves lattices beyond 16-bit indices
+            try:
+                coords, node_ij, tris, tags, n_fan = hostlib.mesh_from_leaves(i0, j0, lev, mat, zc, rc)
+            except RuntimeError as e:
+                raise MeshError(str(e)) from e
+            del mat, allowed
+            return self._finish(coords, node_ij, tris, tags, len(i0), n_fan, nz, nr, h0, lmax, verbose)
         size = np.int64(1) << lev
         i1, j1 = i0 + size, j0 + size
         leaf_mat = mat[i0, j0].astype(np.int32)
@@ -372,22 +381,26 @@ class Mesh:
 
         # element order: Morton code of the owning leaf cell, then the (stable) template order
         eorder = np.argsort(_morton(i0[tcell] + (size[tcell] >> 1), j0[tcell] + (size[tcell] >> 1)), kind="stable")
-        self.coords = coords
-        self.node_ij = node_ij.astype(np.int64)
-        self.tris = tris[eorder].astype(np.int32)
         # cell tag = gmsh surface id: 1-based in material list order (reference mesh.py:114)
-        self.tags = (tmat[eorder] + 1).astype(np.int32)
-        for k, m in enumerate(mats):
+        return self._finish(coords, node_ij.astype(np.int64), tris[eorder].astype(np.int32), (tmat[eorder] + 1).astype(np.int32),
+                            len(i0), int(fan.sum()), nz, nr, h0, lmax, verbose)
+
+    def _finish(self, coords, node_ij, tris, tags, n_leaves, n_fan, nz, nr, h0, lmax, verbose):
+        self.coords = coords
+        self.node_ij = node_ij
+        self.tris = tris
+        self.tags = tags
+        for k, m in enumerate(self.materials):
             m._tag = k + 1
             m.tag = k + 1
             self.material_tags[m.name] = k + 1
         self.stats = {
-            "n_nodes": int(n_nodes), "n_tris": int(len(tris)), "n_leaves": int(len(i0)),
+            "n_nodes": int(len(coords)), "n_tris": int(len(tris)), "n_leaves": int(n_leaves),
             "base_grid": (int(nz), int(nr)), "h0": float(h0), "max_level": int(lmax),
-            "n_fan_cells": int(fan.sum()),
+            "n_fan_cells": int(n_fan),
         }
         if verbose:
-            print(f"mesh: {n_nodes} nodes, {len(tris)} triangles, base grid {nz}x{nr}, levels 0..{lmax}")
+            print(f"mesh: {len(coords)} nodes, {len(tris)} triangles, base grid {nz}x{nr}, levels 0..{lmax}")
         return self
 
     # -- I/O ----------------------------------------------------------------------------

@@ -34,6 +34,20 @@ int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* ma
 int64_t hfh_quadtree_leaves(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* level, int64_t cap, int64_t* i0,
                             int64_t* j0, int64_t* lev);
 
+/* Nodes and triangles of the mesh from the quadtree's leaves (second half of Mesh.build_mesh, replaces gmsh's meshing of
+ * mesh.py:81-149 together with the functions above).  i0 / j0 / lev: the leaves (hfh_quadtree_leaves); mat: the padded
+ * material map; zc (nz + 1) / rc (nr + 1): the base grid's coordinates.  A leaf with a neighbour's corner on an edge midpoint
+ * ("hanging node") becomes a fan around its centre, every other leaf two right triangles; nodes are numbered and triangles
+ * listed in Morton order (low 16 bits of the lattice indices: nzp, nrp <= 65535, else -EINVAL and the caller's numpy path),
+ * triangles counter-clockwise in (z, r), tag = material index + 1.  -EDOM: a degenerate triangle.  The result is held by
+ * the handle: sizes, then fetch into caller arrays (coords n x 2, node_ij n x 2, tris nt x 3, tags nt), then free. */
+typedef struct hfh_mesh hfh_mesh;
+int hfh_mesh_build(int64_t nleaf, const int64_t* i0, const int64_t* j0, const int64_t* lev, int32_t nzp, int32_t nrp,
+                   const int8_t* mat, int32_t nz, int32_t nr, const double* zc, const double* rc, hfh_mesh** out);
+int hfh_mesh_sizes(const hfh_mesh* h, int64_t* n_nodes, int64_t* n_tris, int64_t* n_fan);
+int hfh_mesh_fetch(const hfh_mesh* h, double* coords, int64_t* node_ij, int32_t* tris, int32_t* tags);
+void hfh_mesh_free(hfh_mesh* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,7 @@ def test_mesher_is_deterministic_and_grades_into_the_diamond():
     a = build_case("geballe_with_diamond", 8.0)[2]
     b = build_case("geballe_with_diamond", 8.0)[2]
     assert np.array_equal(a.coords, b.coords) and np.array_equal(a.tris, b.tris) and np.array_equal(a.tags, b.tags)
+    assert np.array_equal(a.node_ij, b.node_ij) and a.stats == b.stats and a.tris.dtype == b.tris.dtype and a.tags.dtype == b.tags.dtype
     assert a.stats["max_level"] >= 5 and a.stats["n_fan_cells"] > 0
     # far fewer nodes than a tensor grid at the finest spacing would need
     assert a.stats["n_nodes"] < 0.02 * a.stats["base_grid"][0] * a.stats["base_grid"][1]
@@ -252,7 +253,7 @@ def test_mesher_on_random_layer_stacks(seed):
     # the native quadtree passes (libheatflow_host.so) and their numpy statement give the same mesh, bit for bit
     other = Mesh("m", [z[0], z[-1], 0.0, max(m.boundaries[3] for m in mats)], mats).build_mesh(use_native=False)
     assert np.array_equal(mesh.coords, other.coords) and np.array_equal(mesh.tris, other.tris)
-    assert np.array_equal(mesh.tags, other.tags)
+    assert np.array_equal(mesh.tags, other.tags) and np.array_equal(mesh.node_ij, other.node_ij) and mesh.stats == other.stats
     c, t = mesh.coords, mesh.tris
     p0, p1, p2 = c[t[:, 0]], c[t[:, 1]], c[t[:, 2]]
     area = 0.5 * ((p1[:, 0] - p0[:, 0]) * (p2[:, 1] - p0[:, 1]) - (p2[:, 0] - p0[:, 0]) * (p1[:, 1] - p0[:, 1]))
