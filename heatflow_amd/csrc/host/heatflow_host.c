@@ -271,22 +271,43 @@ int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* ma
 }
 
 /* Leaves of the level map in the mesher's order: by level, row-major within a level.  Writes up to `cap`
- * (i0, j0, lev) triples and returns the total count (call with cap = 0 to size the arrays). */
+ * (i0, j0, lev) triples and returns the total count (call with cap = 0 to size the arrays).  Row-parallel: a counting pass
+ * per level gives every row its place in the list, a second pass fills it. */
+typedef struct { const int8_t* level; int32_t nrp, hr; int lv; int64_t* rowcnt; int64_t cap; int64_t *i0, *j0, *lev; } leaves_arg;
+static void leaves_count_rows(int32_t a, int32_t b, void* p) {
+  leaves_arg* g = (leaves_arg*)p;
+  for (int32_t i = a; i < b; ++i) {
+    const int8_t* row = g->level + ((size_t)i << g->lv) * g->nrp;
+    int64_t c = 0;
+    for (int32_t j = 0; j < g->hr; ++j) c += row[(size_t)j << g->lv] == g->lv;
+    g->rowcnt[i] = c;
+  }
+}
+static void leaves_fill_rows(int32_t a, int32_t b, void* p) {
+  leaves_arg* g = (leaves_arg*)p;
+  for (int32_t i = a; i < b; ++i) {
+    const int8_t* row = g->level + ((size_t)i << g->lv) * g->nrp;
+    int64_t at = g->rowcnt[i];                     /* after the prefix sum: the row's first position in the list */
+    for (int32_t j = 0; j < g->hr && at < g->cap; ++j)
+      if (row[(size_t)j << g->lv] == g->lv) { g->i0[at] = (int64_t)i << g->lv; g->j0[at] = (int64_t)j << g->lv; g->lev[at] = g->lv; ++at; }
+  }
+}
 int64_t hfh_quadtree_leaves(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* level, int64_t cap, int64_t* i0,
                             int64_t* j0, int64_t* lev) {
   if (nzp <= 0 || nrp <= 0 || lmax < 0 || lmax > 30 || !level) return -EINVAL;
+  if (cap > 0 && (!i0 || !j0 || !lev)) return -EINVAL;
+  int64_t* rowcnt = (int64_t*)malloc(sizeof(int64_t) * (size_t)nzp);
+  if (!rowcnt) return -ENOMEM;
   int64_t cnt = 0;
   for (int lv = 0; lv <= lmax; ++lv) {
     const int32_t hz = nzp >> lv, hr = nrp >> lv;
-    for (int32_t i = 0; i < hz; ++i) {
-      const int8_t* row = level + ((size_t)i << lv) * nrp;
-      for (int32_t j = 0; j < hr; ++j)
-        if (row[(size_t)j << lv] == lv) {
-          if (cnt < cap) { i0[cnt] = (int64_t)i << lv; j0[cnt] = (int64_t)j << lv; lev[cnt] = lv; }
-          ++cnt;
-        }
-    }
+    if (hz <= 0 || hr <= 0) break;
+    leaves_arg g = {level, nrp, hr, lv, rowcnt, cap, i0, j0, lev};
+    par_rows(hz, (size_t)hz * hr, leaves_count_rows, &g);
+    for (int32_t i = 0; i < hz; ++i) { const int64_t c = rowcnt[i]; rowcnt[i] = cnt; cnt += c; }
+    if (cap > 0) par_rows(hz, (size_t)hz * hr, leaves_fill_rows, &g);
   }
+  free(rowcnt);
   return cnt;
 }
 
