@@ -157,6 +157,62 @@ static void pyr0_rows(int32_t i0, int32_t i1, void* p) {
   for (size_t q = (size_t)i0 * a->nrp; q < (size_t)i1 * a->nrp; ++q) a->out[q] = a->level[q] < 0 ? 127 : a->level[q];
 }
 
+typedef struct { const int8_t *mn, *mx, *al; int8_t* ok; int32_t nr; int lv; int any; } ok_arg;
+static void ok_rows(int32_t i0, int32_t i1, void* p) {                  /* one material and nothing finer asked for over the block */
+  ok_arg* a = (ok_arg*)p;
+  int any = 0;
+  for (size_t q = (size_t)i0 * a->nr; q < (size_t)i1 * a->nr; ++q) {
+    const int8_t v = (int8_t)(a->mn[q] == a->mx[q] && a->mn[q] >= 0 && a->al[q] >= a->lv);
+    a->ok[q] = v; any |= v;
+  }
+  if (any) __atomic_store_n(&a->any, 1, __ATOMIC_RELAXED);
+}
+/* 2:1 balance, one level: blocks of level lv whose 8 neighbours hold something finer than lv - 1 are marked (read-only pass on
+ * the unpatched map of that level), then demoted: the block on the finer pyramid levels and in the level map is rewritten.
+ * Blocks are disjoint, so both passes are row-parallel. */
+typedef struct { grid8* g; grid8* pyr; int8_t* level; uint8_t* mark; int32_t nrp; int lv; int changed; } bal_arg;
+static void bal_mark_rows(int32_t i0, int32_t i1, void* p) {
+  bal_arg* a = (bal_arg*)p;
+  const grid8* g = a->g;
+  const int lv = a->lv;
+  for (int32_t i = i0; i < i1; ++i)
+    for (int32_t j = 0; j < g->nr; ++j) {
+      uint8_t dem = 0;
+      if (g->p[(size_t)i * g->nr + j] == lv) {
+        int8_t m = 127;
+        for (int di = -1; di <= 1; ++di) {
+          const int32_t r = i + di; if (r < 0 || r >= g->nz) continue;
+          for (int dj = -1; dj <= 1; ++dj) {
+            const int32_t c = j + dj; if (c < 0 || c >= g->nr || (di == 0 && dj == 0)) continue;
+            const int8_t v = g->p[(size_t)r * g->nr + c]; if (v < m) m = v;
+          }
+        }
+        dem = (uint8_t)(m < lv - 1);
+      }
+      a->mark[(size_t)i * g->nr + j] = dem;
+    }
+}
+static void bal_apply_rows(int32_t i0, int32_t i1, void* p) {
+  bal_arg* a = (bal_arg*)p;
+  grid8* g = a->g;
+  const int lv = a->lv;
+  int changed = 0;
+  for (int32_t i = i0; i < i1; ++i)
+    for (int32_t j = 0; j < g->nr; ++j) {
+      if (!a->mark[(size_t)i * g->nr + j]) continue;
+      g->p[(size_t)i * g->nr + j] = (int8_t)(lv - 1);
+      for (int l = 0; l < lv; ++l) {              /* the block on the finer pyramid levels and in the level map */
+        const int32_t s = 1 << (lv - l);
+        grid8* f = &a->pyr[l];
+        for (int32_t r = i * s; r < (i + 1) * s; ++r) memset(f->p + (size_t)r * f->nr + (size_t)j * s, lv - 1, (size_t)s);
+      }
+      const int32_t s0 = 1 << lv;
+      for (int32_t r = i * s0; r < (i + 1) * s0; ++r) memset(a->level + (size_t)r * a->nrp + (size_t)j * s0, lv - 1, (size_t)s0);
+      changed = 1;
+    }
+  if (changed) __atomic_store_n(&a->changed, 1, __ATOMIC_RELAXED);
+}
+
 int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* mat, const int8_t* allowed, int8_t* level) {
   if (nzp <= 0 || nrp <= 0 || lmax < 0 || lmax > 30 || !mat || !allowed || !level) return -EINVAL;
   if ((nzp & ((1 << lmax) - 1)) || (nrp & ((1 << lmax) - 1))) return -EINVAL;
@@ -171,16 +227,13 @@ int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* ma
     const grid8 a0 = {(int8_t*)allowed, nzp, nrp}, m0 = {(int8_t*)mat, nzp, nrp};
     const grid8 *pa = &a0, *pmin = &m0, *pmax = &m0;
     for (int lv = 1; lv <= lmax && rc == 0; ++lv) {
-      grid8 na, nmin, nmax;
+      grid8 na = {0}, nmin = {0}, nmax = {0};
       const int32_t hz = nzp >> lv, hr = nrp >> lv;
       if (grid_alloc(&na, hz, hr) || grid_alloc(&nmin, hz, hr) || grid_alloc(&nmax, hz, hr) || grid_alloc(&ok[lv], hz, hr)) { rc = -ENOMEM; free(na.p); free(nmin.p); free(nmax.p); break; }
       reduce_min(pa, &na); reduce_min(pmin, &nmin); reduce_max(pmax, &nmax);
-      int any = 0;
-      const size_t M = (size_t)hz * hr;
-      for (size_t q = 0; q < M; ++q) {
-        const int8_t v = (int8_t)(nmin.p[q] == nmax.p[q] && nmin.p[q] >= 0 && na.p[q] >= lv);
-        ok[lv].p[q] = v; any |= v;
-      }
+      ok_arg oa = {nmin.p, nmax.p, na.p, ok[lv].p, hr, lv, 0};
+      par_rows(hz, (size_t)hz * hr * 4, ok_rows, &oa);
+      const int any = oa.any;
       free(amin.p); free(mmin.p); free(mmax.p);
       amin = na; mmin = nmin; mmax = nmax; pa = &amin; pmin = &mmin; pmax = &mmax;
       if (!any) { free(ok[lv].p); ok[lv].p = NULL; break; }
@@ -211,7 +264,6 @@ int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* ma
   /* ---- 2:1 balance with smooth grading: a level-L leaf needs each of its 8 same-size neighbour blocks to
    * hold nothing finer than L-1.  Each sweep walks the levels upwards on a min-pyramid that is patched as
    * blocks are demoted; downward ripples take another sweep. ---- */
-  const int8_t BIG = 127;
   grid8* pyr = (grid8*)calloc((size_t)lmax + 1, sizeof(grid8));
   if (!pyr) return -ENOMEM;
   for (int lv = 0; lv <= lmax; ++lv)
@@ -223,6 +275,8 @@ int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* ma
     par_rows(nzp, N, pyr0_rows, &pa0);
     if (lmax >= 1) reduce_min(&pyr[0], &pyr[1]);
   }
+  uint8_t* mark = (uint8_t*)malloc(lmax >= 2 ? (size_t)(nzp >> 2) * (size_t)(nrp >> 2) : 1);   /* level 2 has the most blocks */
+  if (!mark) rc = -ENOMEM;
   int converged = 0;
   for (int sweep = 0; sweep < 2 * (lmax + 2) && rc == 0; ++sweep) {
     int changed = 0;
@@ -230,40 +284,14 @@ int hfh_quadtree_levels(int32_t nzp, int32_t nrp, int32_t lmax, const int8_t* ma
       reduce_min(&pyr[lv - 1], &pyr[lv]);
       grid8* g = &pyr[lv];
       /* demotions of one level are decided on the unpatched map of that level (as the vectorised original does) */
-      size_t ndem = 0, cap = 0; int32_t* dem = NULL;
-      for (int32_t i = 0; i < g->nz; ++i)
-        for (int32_t j = 0; j < g->nr; ++j) {
-          if (g->p[(size_t)i * g->nr + j] != lv) continue;
-          int8_t m = BIG;
-          for (int di = -1; di <= 1; ++di) {
-            const int32_t a = i + di; if (a < 0 || a >= g->nz) continue;
-            for (int dj = -1; dj <= 1; ++dj) {
-              const int32_t b = j + dj; if (b < 0 || b >= g->nr || (di == 0 && dj == 0)) continue;
-              const int8_t v = g->p[(size_t)a * g->nr + b]; if (v < m) m = v;
-            }
-          }
-          if (m < lv - 1) {
-            if (ndem == cap) { cap = cap ? 2 * cap : 1024; int32_t* t = (int32_t*)realloc(dem, cap * 2 * sizeof(int32_t)); if (!t) { rc = -ENOMEM; break; } dem = t; }
-            dem[2 * ndem] = i; dem[2 * ndem + 1] = j; ++ndem;
-          }
-        }
-      for (size_t q = 0; q < ndem && rc == 0; ++q) {
-        const int32_t i = dem[2 * q], j = dem[2 * q + 1];
-        g->p[(size_t)i * g->nr + j] = (int8_t)(lv - 1);
-        for (int l = 0; l < lv; ++l) {              /* the block on the finer pyramid levels and in the level map */
-          const int32_t s = 1 << (lv - l);
-          grid8* f = &pyr[l];
-          for (int32_t a = i * s; a < (i + 1) * s; ++a) memset(f->p + (size_t)a * f->nr + (size_t)j * s, lv - 1, (size_t)s);
-        }
-        const int32_t s0 = 1 << lv;
-        for (int32_t a = i * s0; a < (i + 1) * s0; ++a) memset(level + (size_t)a * nrp + (size_t)j * s0, lv - 1, (size_t)s0);
-        changed = 1;
-      }
-      free(dem);
-      if (rc) break;
+      bal_arg ba = {g, pyr, level, mark, nrp, lv, 0};
+      par_rows(g->nz, (size_t)g->nz * g->nr * 8, bal_mark_rows, &ba);
+      par_rows(g->nz, (size_t)g->nz * g->nr * 8, bal_apply_rows, &ba);
+      changed |= ba.changed;
     }
     if (!changed) { converged = 1; break; }
   }
+  free(mark);
   for (int lv = 0; lv <= lmax; ++lv) free(pyr[lv].p);
   free(pyr);
   if (rc) return rc;
