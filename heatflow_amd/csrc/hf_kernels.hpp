@@ -1417,31 +1417,108 @@ __global__ void k_to_float(size_t n, const double* __restrict__ src, float* __re
     dst[i] = static_cast<float>(src[i]);
 }
 
-// Dense inverse of the coarsest operator on the GPU: Gauss-Jordan without pivoting (the operator
-// is SPD, its pivots stay positive).  Two launches per pivot; A is overwritten by the identity.
-__global__ __launch_bounds__(TPB) void k_gj_pivot(int n, int c, const double* __restrict__ A,
-                                                  const double* __restrict__ Inv, double* __restrict__ prow,
-                                                  double* __restrict__ pcol) {
-  const double piv = A[static_cast<size_t>(c) * n + c];
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) {
-    prow[j] = A[static_cast<size_t>(c) * n + j] / piv;
-    prow[n + j] = Inv[static_cast<size_t>(c) * n + j] / piv;
-    pcol[j] = A[static_cast<size_t>(j) * n + c];
+// Dense inverse of the coarsest operator on the GPU: blocked Gauss-Jordan without pivoting (the operator is SPD, its pivots
+// stay positive).  W = [A | I] (n x 2n, row pitch 2n) is reduced to [I | A^-1], GJ_B pivots per step.  At the step of pivot block
+// [c0, c0 + b) only the n columns [c0 + b, n + c0 + b) can still change (those to the left of the block are finished unit columns
+// and never read again, those to the right of the window still hold the identity's zeros), so a step is
+//   k_gjb_rows:   R = D^-1 W(block rows, window), D = W(block, block) inverted in LDS by every workgroup for itself
+//   k_gjb_update: W(i, window) -= W(i, block) R for the rows outside the block, W(block rows, window) = R
+// - n^2 entries read and written per GJ_B pivots instead of 2 n^2 per pivot (1634 rows: 85 MB per pivot before, 30 ms in all).
+constexpr int GJ_B = 32;
+__global__ __launch_bounds__(TPB) void k_gjb_rows(int n, int c0, int b, const double* __restrict__ W, double* __restrict__ R /* [GJ_B][n] */) {
+  __shared__ double D[GJ_B][GJ_B + 1], Di[GJ_B][GJ_B + 1];
+  const int t = threadIdx.x, ld = 2 * n;
+  for (int q = t; q < GJ_B * GJ_B; q += TPB) {
+    const int r = q / GJ_B, c = q % GJ_B;
+    D[r][c] = (r < b && c < b) ? W[static_cast<size_t>(c0 + r) * ld + c0 + c] : (r == c ? 1.0 : 0.0);
+    Di[r][c] = r == c ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int p = 0; p < b; ++p) {                    // Gauss-Jordan on [D | Di], one pivot per round
+    const double piv = D[p][p];
+    __syncthreads();
+    for (int q = t; q < 2 * GJ_B; q += TPB) {
+      if (q < GJ_B) D[p][q] /= piv; else Di[p][q - GJ_B] /= piv;
+    }
+    __syncthreads();
+    for (int q = t; q < GJ_B * 2 * GJ_B; q += TPB) {
+      const int r = q / (2 * GJ_B), c = q % (2 * GJ_B);
+      if (r == p) continue;
+      const double f = D[r][p];
+      if (c < GJ_B) { if (c != p) D[r][c] -= f * D[p][c]; } else Di[r][c - GJ_B] -= f * Di[p][c - GJ_B];
+    }
+    __syncthreads();
+    for (int r = t; r < GJ_B; r += TPB)
+      if (r != p) D[r][p] = 0.0;
+    __syncthreads();
+  }
+  // this workgroup's columns of the window
+  for (int j = blockIdx.x * TPB + t; j < n; j += gridDim.x * TPB) {
+    const size_t col = static_cast<size_t>(c0 + b + j);
+    double w[GJ_B];
+#pragma unroll
+    for (int r = 0; r < GJ_B; ++r) w[r] = r < b ? W[static_cast<size_t>(c0 + r) * ld + col] : 0.0;
+    for (int r = 0; r < b; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < GJ_B; ++c) s += Di[r][c] * w[c];
+      R[static_cast<size_t>(r) * n + j] = s;
+    }
   }
 }
 
-__global__ __launch_bounds__(TPB) void k_gj_elim(int n, int c, double* __restrict__ A, double* __restrict__ Inv,
-                                                 const double* __restrict__ prow, const double* __restrict__ pcol) {
-  const size_t total = static_cast<size_t>(n) * n;
-  for (size_t q = static_cast<size_t>(blockIdx.x) * TPB + threadIdx.x; q < total; q += static_cast<size_t>(gridDim.x) * TPB) {
-    const int r = static_cast<int>(q / n), j = static_cast<int>(q % n);
-    if (r == c) {
-      A[q] = prow[j];
-      Inv[q] = prow[n + j];
-    } else {
-      const double f = pcol[r];
-      A[q] -= f * prow[j];
-      Inv[q] -= f * prow[n + j];
+// W = [A | I] from the coarsest operator in CSR form (W zeroed before): a thread per row
+__global__ void k_gjb_fill(int n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const double* __restrict__ val,
+                           double* __restrict__ W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double* w = W + static_cast<size_t>(i) * 2 * n;
+  for (int k = ptr[i]; k < ptr[i + 1]; ++k) w[idx[k]] = val[k];
+  w[n + i] = 1.0;
+}
+
+// 64 x 64 tile of the window per workgroup, 4 x 4 entries per thread; the tile's slices of the pivot columns and of R in LDS
+__global__ __launch_bounds__(TPB) void k_gjb_update(int n, int c0, int b, double* __restrict__ W, const double* __restrict__ R) {
+  __shared__ double sC[64][GJ_B + 1], sR[GJ_B][64 + 1];
+  const int ld = 2 * n, t = threadIdx.x;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  for (int q = t; q < 64 * GJ_B; q += TPB) {
+    const int r = q / GJ_B, c = q % GJ_B;
+    sC[r][c] = (i0 + r < n && c < b) ? W[static_cast<size_t>(i0 + r) * ld + c0 + c] : 0.0;
+  }
+  for (int q = t; q < GJ_B * 64; q += TPB) {
+    const int r = q / 64, c = q % 64;
+    sR[r][c] = (r < b && j0 + c < n) ? R[static_cast<size_t>(r) * n + j0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int ti = (t / 16) * 4, tj = (t % 16) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+  for (int k = 0; k < GJ_B; ++k) {
+    double cu[4], rv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cu[u] = sC[ti + u][k];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) rv[v] = sR[k][tj + v];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] += cu[u] * rv[v];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = i0 + ti + u;
+    if (i >= n) continue;
+    const bool pivot_row = i >= c0 && i < c0 + b;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int j = j0 + tj + v;
+      if (j >= n) continue;
+      double* w = W + static_cast<size_t>(i) * ld + c0 + b + j;
+      *w = pivot_row ? sR[i - c0][tj + v] : *w - acc[u][v];
     }
   }
 }

@@ -201,30 +201,35 @@ int finish_amg(hf_ctx* ctx, const amg::Csr& Ac, int coarse_n, double op_complexi
   if (nl > 1 && coarse_n > 0 && coarse_n <= 4096) {
     const int nc = coarse_n;
     const int ld = (nc + 3) & ~3;
-    std::vector<double> dense(static_cast<size_t>(nc) * nc, 0.0), eye(static_cast<size_t>(nc) * nc, 0.0);
-    for (int i = 0; i < nc; ++i) {
-      for (int k = Ac.ptr[i]; k < Ac.ptr[i + 1]; ++k) dense[static_cast<size_t>(i) * nc + Ac.idx[k]] = Ac.val[k];
-      eye[static_cast<size_t>(i) * nc + i] = 1.0;
-    }
-    DevTemp<double> t_dense, t_inv, t_prow, t_pcol;
-    double *&d_dense = t_dense.p, *&d_inv = t_inv.p, *&d_prow = t_prow.p, *&d_pcol = t_pcol.p;
-    HF_TRY(dev_alloc(ctx, &d_dense, dense.size()));
-    HF_TRY(dev_alloc(ctx, &d_inv, eye.size()));
+    for (int i = 0; i < nc; ++i)
+      for (int k = Ac.ptr[i]; k < Ac.ptr[i + 1]; ++k)
+        if (Ac.idx[k] < 0 || Ac.idx[k] >= nc) return fail(ctx, HF_ERR_ARG, "coarsest operator: column %d outside [0,%d)", Ac.idx[k], nc);
+    // W = [A | I] on the device (the operator travels in CSR form), blocked Gauss-Jordan (hf_kernels.hpp), A^-1 = the right half
+    DevTemp<double> t_w, t_r, t_val;
+    DevTemp<int32_t> t_ptr, t_idx;
+    HF_TRY(dev_alloc(ctx, &t_w.p, static_cast<size_t>(nc) * 2 * nc));
+    HF_TRY(dev_alloc(ctx, &t_r.p, static_cast<size_t>(GJ_B) * nc));
+    HF_TRY(dev_alloc(ctx, &t_ptr.p, Ac.ptr.size()));
+    HF_TRY(dev_alloc(ctx, &t_idx.p, std::max<size_t>(Ac.idx.size(), 1)));
+    HF_TRY(dev_alloc(ctx, &t_val.p, std::max<size_t>(Ac.val.size(), 1)));
     HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv, static_cast<size_t>(nc) * ld));
-    HF_TRY(dev_alloc(ctx, &d_prow, 2 * static_cast<size_t>(nc)));
-    HF_TRY(dev_alloc(ctx, &d_pcol, static_cast<size_t>(nc)));
-    HF_HIP(copy_sync(ctx, d_dense, dense.data(), sizeof(double) * dense.size(), hipMemcpyHostToDevice));
-    HF_HIP(copy_sync(ctx, d_inv, eye.data(), sizeof(double) * eye.size(), hipMemcpyHostToDevice));
-    const int gp = std::max(1, (nc + TPB - 1) / TPB);
-    const int ge = static_cast<int>(std::min<size_t>((static_cast<size_t>(nc) * nc + TPB - 1) / TPB, 4096));
-    for (int cpiv = 0; cpiv < nc; ++cpiv) {
-      hipLaunchKernelGGL(k_gj_pivot, dim3(gp), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, d_inv, d_prow, d_pcol);
-      hipLaunchKernelGGL(k_gj_elim, dim3(ge), dim3(TPB), 0, ctx->stream, nc, cpiv, d_dense, d_inv, d_prow, d_pcol);
+    HF_HIP(copy_sync(ctx, t_ptr.p, Ac.ptr.data(), sizeof(int32_t) * Ac.ptr.size(), hipMemcpyHostToDevice));
+    if (!Ac.idx.empty()) {
+      HF_HIP(copy_sync(ctx, t_idx.p, Ac.idx.data(), sizeof(int32_t) * Ac.idx.size(), hipMemcpyHostToDevice));
+      HF_HIP(copy_sync(ctx, t_val.p, Ac.val.data(), sizeof(double) * Ac.val.size(), hipMemcpyHostToDevice));
+    }
+    HF_HIP(hipMemsetAsync(t_w.p, 0, sizeof(double) * nc * 2 * nc, ctx->stream));
+    hipLaunchKernelGGL(k_gjb_fill, dim3((nc + 255) / 256), dim3(256), 0, ctx->stream, nc, t_ptr.p, t_idx.p, t_val.p, t_w.p);
+    const int tiles = (nc + 63) / 64;
+    for (int c0 = 0; c0 < nc; c0 += GJ_B) {
+      const int bsz = std::min(GJ_B, nc - c0);
+      hipLaunchKernelGGL(k_gjb_rows, dim3(std::max(1, std::min((nc + TPB - 1) / TPB, 64))), dim3(TPB), 0, ctx->stream, nc, c0, bsz, t_w.p, t_r.p);
+      hipLaunchKernelGGL(k_gjb_update, dim3(tiles, tiles), dim3(TPB), 0, ctx->stream, nc, c0, bsz, t_w.p, t_r.p);
     }
     HF_HIP(hipGetLastError());
     // rows re-pitched to the even leading dimension (zero pad column)
     HF_HIP(hipMemsetAsync(ctx->d_coarse_inv, 0, sizeof(double) * nc * ld, ctx->stream));
-    HF_HIP(hipMemcpy2DAsync(ctx->d_coarse_inv, sizeof(double) * ld, d_inv, sizeof(double) * nc, sizeof(double) * nc, nc,
+    HF_HIP(hipMemcpy2DAsync(ctx->d_coarse_inv, sizeof(double) * ld, t_w.p + nc, sizeof(double) * 2 * nc, sizeof(double) * nc, nc,
                             hipMemcpyDeviceToDevice, ctx->stream));
     if (f32) {
       HF_TRY(dev_alloc(ctx, &ctx->d_coarse_inv_f, static_cast<size_t>(nc) * ld));
