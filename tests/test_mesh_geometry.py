@@ -341,3 +341,32 @@ def test_msh41_writer_round_trip_keeps_physical_tags(tmp_path):
     cb, tb, gb = load_mesh_arrays(p2)
     assert np.array_equal(ta, tb) and np.array_equal(ga, gb) and np.array_equal(ca, cb)
     assert np.array_equal(_tri_key(ca, ta, ga), _tri_key(mesh.coords, mesh.tris, mesh.tags))
+
+
+def test_native_mesh_construction_limits_and_the_numpy_route_beyond_them(monkeypatch):
+    """hfh_mesh_build numbers nodes and triangles by Morton codes of the low 16 bits of the lattice indices, like the numpy
+    statement; beyond 65535 lattice lines per direction build_mesh keeps the numpy route (same arrays), and the native entry
+    point refuses such a lattice and malformed leaves instead of reading outside its bitmaps."""
+    from heatflow_amd import hostlib
+    from heatflow_amd.geometry import build_stack, scale_mesh_sizes
+
+    stack = build_stack(scale_mesh_sizes(load_cfg("geballe_with_diamond"), 8.0))
+    ref = Mesh("a", stack.bounds, stack.materials).build_mesh(use_native=True)
+    monkeypatch.setattr(hostlib, "MESH_LATTICE_MAX", 16)          # every real lattice is "too large" now
+    called = []
+    monkeypatch.setattr(hostlib, "mesh_from_leaves", lambda *a, **k: called.append(1))
+    other = Mesh("b", stack.bounds, stack.materials).build_mesh(use_native=True)
+    assert not called
+    assert np.array_equal(ref.coords, other.coords) and np.array_equal(ref.tris, other.tris) and np.array_equal(ref.tags, other.tags)
+    monkeypatch.undo()
+    i0 = np.array([0, 2], dtype=np.int64)
+    j0 = np.array([0, 0], dtype=np.int64)
+    lev = np.array([1, 1], dtype=np.int64)
+    mat = np.zeros((4, 2), dtype=np.int8)
+    zc, rc = np.linspace(0.0, 1.0, 5), np.linspace(0.0, 1.0, 3)
+    coords, node_ij, tris, tags, n_fan = hostlib.mesh_from_leaves(i0, j0, lev, mat, zc, rc)       # two 2 x 2 leaves side by side
+    assert len(coords) == 6 and len(tris) == 4 and n_fan == 0 and set(tags) == {1}
+    with pytest.raises(RuntimeError):                                  # a leaf sticking out of the lattice
+        hostlib.mesh_from_leaves(np.array([4], dtype=np.int64), j0[:1], lev[:1], mat, zc, rc)
+    with pytest.raises(RuntimeError):                                  # more lattice lines than 16-bit Morton codes order
+        hostlib.mesh_from_leaves(i0, j0, lev, np.zeros((4, 70000), dtype=np.int8), zc, np.linspace(0.0, 1.0, 70001))
